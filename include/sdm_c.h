@@ -1,0 +1,176 @@
+/*
+ * sdm_c.h -- C ABI of the MI355X semi-dense mapping engine (libsdm_hip.so).
+ *
+ * Drop-in boundary for the ProbabilityMapping hot path of atlas-jj/ORB-SLAM-free-space-carving.
+ * The reference has no FFI/plugin registry for this path -- it is a plain C++ class
+ * (/root/reference/include/Modeler/ProbabilityMapping.h:61-105, "PM.h").  Each entry point below
+ * names the reference method it replaces; include/sdm/ProbabilityMapping.h keeps the reference's
+ * class surface and forwards here.  Plain pointers and sizes only; no torch/HIP types.
+ *
+ * Conventions
+ *  - "rho" is INVERSE depth (PM.cc:352-353: Z = 1/inv_d); maps are row-major, stride W.
+ *  - keyframes live in numbered device slots [0, max_keyframes); all share W x H.
+ *  - every call returns 0 on success or an SDM_E* code; sdm_last_error() has the text.  The
+ *    reference's methods are void and unchecked (PM.cc passim); the C++ wrapper logs to cerr.
+ *  - a context is single-caller (not re-entrant), like the reference's single mapping thread
+ *    (PM.cc:65-87).  Work is queued on the context's HIP stream; host-pointer calls synchronise.
+ *  - there is NO CPU fallback: without a visible gfx950 device sdm_create fails.
+ */
+#ifndef SDM_C_H
+#define SDM_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDM_OK 0
+#define SDM_EINVAL 1   /* bad argument (slot, size, null pointer, n > max_neighbours ...) */
+#define SDM_EHIP 2     /* HIP runtime error (text in sdm_last_error) */
+#define SDM_ENODEV 3   /* no usable GPU */
+#define SDM_ESTATE 4   /* slot not uploaded / stage not run yet */
+
+#define SDM_MAX_NEIGHBOURS 64
+
+typedef struct sdm_ctx sdm_ctx;
+
+/* PM.h:38-49 macros as runtime parameters (defaults = the reference's values). */
+typedef struct {
+    float lambdaG;     /* 8    PM.h:40  gradient gate (PM.cc:201,411,562)          */
+    float lambdaL;     /* 80   PM.h:41  epipolar-line angle gate, deg (PM.cc:421)   */
+    float lambdaTheta; /* 45   PM.h:42  orientation gate, deg (PM.cc:431)           */
+    int lambdaN;       /* 3    PM.h:43  (PM.cc:221 '>', :623 '>=', :762 '<')        */
+    double theta_var;  /* 0.23 PM.h:47  THETA, a double literal (PM.cc:436,455-456) */
+} sdm_params;
+
+typedef struct {
+    int device;           /* HIP device ordinal */
+    int W, H;             /* image size shared by all keyframes */
+    int max_keyframes;    /* number of device slots */
+    int max_neighbours;   /* <= SDM_MAX_NEIGHBOURS; reference covisN = 7 (PM.h:38) */
+    int batch_capacity;   /* keyframes processed per launch group (scratch size); 0 = default */
+    int with_pointset;    /* allocate the xyz pool (12 B/px/keyframe) for sdm_pointset */
+    void *ext_depth_pool; /* optional caller-owned DEVICE buffer of sdm_depth_pool_bytes(); lets the
+                             host framework (e.g. torch.distributed/RCCL) all-gather it in place */
+    void *stream;         /* optional hipStream_t to run on (NULL = context-owned stream) */
+} sdm_config;
+
+typedef struct {
+    long long searches;   /* EpipolarSearch invocations (pixel, neighbour)  PM.cc:213 */
+    long long candidates; /* scan-loop iterations                           PM.cc:405 */
+    long long gate_pass;  /* candidates that reached the cost               PM.cc:433 */
+    long long hypotheses; /* accepted hypotheses                            PM.cc:216 */
+    long long fused;      /* pixels written                                 PM.cc:225 */
+} sdm_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+void sdm_default_params(sdm_params *p);
+void sdm_default_config(sdm_config *c);
+size_t sdm_depth_pool_bytes(int W, int H, int max_keyframes); /* = 8*W*H*max_keyframes */
+int sdm_create(sdm_ctx **out, const sdm_config *cfg); /* replaces ProbabilityMapping(Map*) PM.cc:61 */
+void sdm_destroy(sdm_ctx *ctx);
+const char *sdm_last_error(void);
+int sdm_set_params(sdm_ctx *ctx, const sdm_params *p);
+int sdm_set_stream(sdm_ctx *ctx, void *hip_stream);
+int sdm_synchronize(sdm_ctx *ctx);
+int sdm_device_count(void); /* number of visible HIP devices, 0 if none; never initialises a context */
+
+/* ---- keyframe inputs (the KeyFrame members PM.cc reads) --------------------- */
+/* im_: H*W u8; GradImg, GradTheta (degrees [0,360)): H*W f32; I_stddev; K = {fx,fy,cx,cy}
+ * (include/KeyFrame.h:162); Tcw = world->camera [R|t] row-major 3x4 (src/KeyFrame.cc:70-121). */
+int sdm_upload_keyframe(sdm_ctx *ctx, int slot, const uint8_t *im, const float *grad,
+                        const float *theta, float I_stddev, const float K[4], const float Tcw[12]);
+/* gray image only: GradImg/GradTheta/I_stddev computed on device (Scharr/32, magnitude,
+ * fastAtan2 phase, population sigma) -- the pre-processing the reference leaves to the caller. */
+int sdm_upload_image(sdm_ctx *ctx, int slot, const uint8_t *im, const float K[4],
+                     const float Tcw[12]);
+/* same, image already resident in device memory */
+int sdm_upload_image_device(sdm_ctx *ctx, int slot, const void *d_im, const float K[4],
+                            const float Tcw[12]);
+/* pose changed after bundle adjustment (kf->poseChanged, PM.cc:329) */
+int sdm_set_pose(sdm_ctx *ctx, int slot, const float Tcw[12]);
+/* read back what the device derived for a slot (for tests): any pointer may be NULL */
+int sdm_download_inputs(sdm_ctx *ctx, int slot, uint8_t *im, float *grad, float *theta,
+                        float *I_stddev);
+
+/* ---- SemiDenseRecon, PM.h:75 / PM.cc:137-256, batched over n_ref reference keyframes --------- */
+/* nbr_slots and rot_deg are [n_ref][n]; rot_deg may be NULL (= 0, "kf pair without
+ * covisibility", PM.cc:174-177).  min_depth/max_depth are [n_ref], named as in PM.cc:381-382. */
+int sdm_search_fuse(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *nbr_slots,
+                    const float *rot_deg, const float *min_depth,
+                    const float *max_depth);                            /* PM.cc:197-231 */
+int sdm_intra_check(sdm_ctx *ctx, int n_ref, const int *ref_slots);     /* PM.cc:486-547 */
+int sdm_intra_grow(sdm_ctx *ctx, int n_ref, const int *ref_slots);      /* PM.cc:549-596 */
+int sdm_recon(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *nbr_slots,
+              const float *rot_deg, const float *min_depth, const float *max_depth);
+
+/* ---- InterKeyFrameDepthChecking, PM.h:91 / PM.cc:628-799 -------------------------------------- */
+/* Reads the neighbours' current {rho,sigma}; writes the checked rho of each reference keyframe to
+ * its "checked" plane.  commit != 0 also stores it back into the keyframe's depth map, which is
+ * the reference's in-place behaviour (call with n_ref = 1, in the caller's keyframe order). */
+int sdm_inter_check(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *nbr_slots,
+                    int commit);
+
+/* ---- UpdateSemiDensePointSet, PM.h:88 / PM.cc:337-367 ----------------------------------------- */
+/* source: 0 = depth map, 1 = checked plane.  Needs with_pointset. */
+int sdm_pointset(sdm_ctx *ctx, int n_ref, const int *ref_slots, int source);
+
+/* ---- map transfer ------------------------------------------------------------------------------ */
+int sdm_upload_depth(sdm_ctx *ctx, int slot, const float *rho, const float *sigma);
+int sdm_download_depth(sdm_ctx *ctx, int slot, float *rho, float *sigma); /* depth_map_/depth_sigma_ */
+int sdm_download_checked(sdm_ctx *ctx, int slot, float *rho);
+int sdm_download_pointset(sdm_ctx *ctx, int slot, float *xyz);            /* H x 3W */
+/* device addresses for zero-copy interop (RCCL all-gather of per-keyframe {rho,sigma} maps):
+ * the depth pool is [max_keyframes][H][W] of float2 {rho,sigma}. */
+void *sdm_depth_pool_ptr(sdm_ctx *ctx);
+
+/* ---- stand-alone map operations with the reference's signatures -------------------------------- */
+/* IntraKeyFrameDepthChecking(cv::Mat&, cv::Mat&, const cv::Mat) PM.h:85; host maps, in place. */
+int sdm_intra_check_maps(sdm_ctx *ctx, float *rho, float *sigma, const float *grad);
+/* IntraKeyFrameDepthGrowing(cv::Mat&, cv::Mat&, const cv::Mat)  PM.h:86 */
+int sdm_intra_grow_maps(sdm_ctx *ctx, float *rho, float *sigma, const float *grad);
+
+/* ---- per-pixel entry points (unit tests; same device functions as the batched kernels) -------- */
+/* EpipolarSearch PM.h:79: out = {rho, sigma, supported(0/1), best_u, best_v} */
+int sdm_epipolar_search(sdm_ctx *ctx, int ref_slot, int nbr_slot, int x, int y, float min_depth,
+                        float max_depth, float rot_deg, float out[5]);
+/* GetSearchRange PM.h:80 */
+int sdm_search_range(sdm_ctx *ctx, int ref_slot, int nbr_slot, int x, int y, float mind,
+                     float maxd, float *umin, float *umax);
+/* InverseDepthHypothesisFusion PM.h:83: out = {rho, sigma, supported(0/1)} */
+int sdm_fuse(sdm_ctx *ctx, const float *rho, const float *sigma, int n, float out[3]);
+/* ComputeFundamental PM.h:101 and R21/t21 (PM.cc:859-860): F12[9], R21[9], t21[3] */
+int sdm_pair_geometry(sdm_ctx *ctx, int ref_slot, int nbr_slot, float F12[9], float R21[9],
+                      float t21[3]);
+
+/* ---- host helpers of the class surface (no device work) ---------------------------------------- */
+/* StereoSearchConstraints PM.h:77 / PM.cc:370-383 over the keyframe's ORB point depths */
+int sdm_stereo_search_constraints(const float *orb_depths, int n, float *min_depth,
+                                  float *max_depth);
+/* GetRotInPlane PM.h:103 / PM.cc:467-484 + the median of PM.cc:170-179; ids < 0 = no map point */
+float sdm_median_rot_in_plane(const int *mp1, const float *angle1, int n1, const int *mp2,
+                              const float *angle2, int n2);
+
+/* ---- instrumentation ---------------------------------------------------------------------------- */
+/* when enabled, sdm_search_fuse runs its counting variant (slower) and accumulates into stats */
+int sdm_enable_stats(sdm_ctx *ctx, int on);
+int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
+/* per-stage device time measured with HIP events recorded on the context's stream around each
+ * stage's kernel launches (K1 = one k_search_fuse launch per sdm_recon/sdm_search_fuse call) */
+#define SDM_STAGE_SEARCH_FUSE 0 /* K1   PM.cc:197-231 */
+#define SDM_STAGE_INTRA 1       /* K2+K3 PM.cc:237-238 */
+#define SDM_STAGE_INTER 2       /* K4   PM.cc:628-799 */
+#define SDM_STAGE_POINTSET 3    /* K5   PM.cc:337-367 */
+#define SDM_NUM_STAGES 4
+int sdm_enable_timing(sdm_ctx *ctx, int on);
+int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long launches[SDM_NUM_STAGES],
+                   int reset);
+/* name of the device the context runs on, e.g. "gfx950" */
+const char *sdm_device_arch(sdm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

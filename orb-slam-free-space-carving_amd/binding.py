@@ -1,0 +1,355 @@
+"""ctypes mirror of include/sdm_c.h.  No compute happens here: every method forwards to the HIP
+library and raises SdmError on a non-zero status.  There is no CPU fallback -- if
+lib/libsdm_hip.so is missing this module fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_NEIGHBOURS = 64
+
+
+class SdmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sdm error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("lambdaG", C.c_float), ("lambdaL", C.c_float), ("lambdaTheta", C.c_float),
+                ("lambdaN", C.c_int), ("theta_var", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("W", C.c_int), ("H", C.c_int), ("max_keyframes", C.c_int),
+                ("max_neighbours", C.c_int), ("batch_capacity", C.c_int), ("with_pointset", C.c_int),
+                ("ext_depth_pool", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("searches", C.c_longlong), ("candidates", C.c_longlong), ("gate_pass", C.c_longlong),
+                ("hypotheses", C.c_longlong), ("fused", C.c_longlong)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libsdm_hip.so")
+
+
+_lib = None
+
+# every symbol include/sdm_c.h declares: (name, restype, argtypes)
+_f32p, _u8p, _ip = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+_ctx = C.c_void_p
+SYMBOLS = [
+    ("sdm_default_params", None, [C.POINTER(Params)]),
+    ("sdm_default_config", None, [C.POINTER(Config)]),
+    ("sdm_depth_pool_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("sdm_create", C.c_int, [C.POINTER(_ctx), C.POINTER(Config)]),
+    ("sdm_destroy", None, [_ctx]),
+    ("sdm_last_error", C.c_char_p, []),
+    ("sdm_set_params", C.c_int, [_ctx, C.POINTER(Params)]),
+    ("sdm_set_stream", C.c_int, [_ctx, C.c_void_p]),
+    ("sdm_synchronize", C.c_int, [_ctx]),
+    ("sdm_device_count", C.c_int, []),
+    ("sdm_upload_keyframe", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p, C.c_float, _f32p, _f32p]),
+    ("sdm_upload_image", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p]),
+    ("sdm_upload_image_device", C.c_int, [_ctx, C.c_int, C.c_void_p, _f32p, _f32p]),
+    ("sdm_set_pose", C.c_int, [_ctx, C.c_int, _f32p]),
+    ("sdm_download_inputs", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p, _f32p]),
+    ("sdm_search_fuse", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, _f32p, _f32p, _f32p]),
+    ("sdm_intra_check", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_intra_grow", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_recon", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, _f32p, _f32p, _f32p]),
+    ("sdm_inter_check", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, C.c_int]),
+    ("sdm_pointset", C.c_int, [_ctx, C.c_int, _ip, C.c_int]),
+    ("sdm_upload_depth", C.c_int, [_ctx, C.c_int, _f32p, _f32p]),
+    ("sdm_download_depth", C.c_int, [_ctx, C.c_int, _f32p, _f32p]),
+    ("sdm_download_checked", C.c_int, [_ctx, C.c_int, _f32p]),
+    ("sdm_download_pointset", C.c_int, [_ctx, C.c_int, _f32p]),
+    ("sdm_depth_pool_ptr", C.c_void_p, [_ctx]),
+    ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    ("sdm_intra_grow_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    ("sdm_epipolar_search", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, _f32p]),
+    ("sdm_search_range", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   _f32p, _f32p]),
+    ("sdm_fuse", C.c_int, [_ctx, _f32p, _f32p, C.c_int, _f32p]),
+    ("sdm_pair_geometry", C.c_int, [_ctx, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
+    ("sdm_stereo_search_constraints", C.c_int, [_f32p, C.c_int, _f32p, _f32p]),
+    ("sdm_median_rot_in_plane", C.c_float, [_ip, _f32p, C.c_int, _ip, _f32p, C.c_int]),
+    ("sdm_enable_stats", C.c_int, [_ctx, C.c_int]),
+    ("sdm_get_stats", C.c_int, [_ctx, C.POINTER(Stats), C.c_int]),
+    ("sdm_enable_timing", C.c_int, [_ctx, C.c_int]),
+    ("sdm_get_timing", C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    ("sdm_device_arch", C.c_char_p, [_ctx]),
+]
+
+
+def load_library():
+    """Loads lib/libsdm_hip.so and binds every symbol of include/sdm_c.h (AttributeError if one
+    is missing).  Raises OSError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise OSError("%s not built: run `python orb-slam-free-space-carving_amd/build.py` "
+                      "(there is no CPU fallback)" % p)
+    lib = C.CDLL(p)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def stereo_search_constraints(depths):
+    lib = load_library()
+    d, dp = _f32(depths)
+    mn, mx = C.c_float(), C.c_float()
+    rc = lib.sdm_stereo_search_constraints(dp, len(d), C.byref(mn), C.byref(mx))
+    if rc:
+        raise SdmError(rc, lib.sdm_last_error().decode())
+    return float(mn.value), float(mx.value)
+
+
+def median_rot_in_plane(mp1, ang1, mp2, ang2):
+    lib = load_library()
+    m1, m1p = _i32(mp1)
+    m2, m2p = _i32(mp2)
+    a1, a1p = _f32(ang1)
+    a2, a2p = _f32(ang2)
+    return float(lib.sdm_median_rot_in_plane(m1p, a1p, len(m1), m2p, a2p, len(m2)))
+
+
+class Engine:
+    """One context = one GPU.  Mirrors the ProbabilityMapping method surface (PM.h:72-91) at
+    keyframe-slot granularity."""
+
+    def __init__(self, W, H, max_keyframes, max_neighbours=7, device=0, batch_capacity=0,
+                 with_pointset=True, ext_depth_pool=None, stream=None):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.sdm_default_config(C.byref(cfg))
+        cfg.device, cfg.W, cfg.H = device, W, H
+        cfg.max_keyframes, cfg.max_neighbours = max_keyframes, max_neighbours
+        cfg.batch_capacity = batch_capacity
+        cfg.with_pointset = 1 if with_pointset else 0
+        cfg.ext_depth_pool = ext_depth_pool
+        cfg.stream = stream
+        self.W, self.H, self.max_keyframes, self.max_neighbours = W, H, max_keyframes, max_neighbours
+        self.ctx = _ctx()
+        self._check(self.lib.sdm_create(C.byref(self.ctx), C.byref(cfg)))
+
+    def _check(self, rc):
+        if rc:
+            raise SdmError(rc, self.lib.sdm_last_error().decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sdm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------------
+    def arch(self):
+        return self.lib.sdm_device_arch(self.ctx).decode()
+
+    def set_params(self, **kw):
+        p = Params()
+        self.lib.sdm_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._check(self.lib.sdm_set_params(self.ctx, C.byref(p)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.sdm_set_stream(self.ctx, stream_ptr))
+
+    def synchronize(self):
+        self._check(self.lib.sdm_synchronize(self.ctx))
+
+    def depth_pool_ptr(self):
+        return self.lib.sdm_depth_pool_ptr(self.ctx)
+
+    # -- inputs ----------------------------------------------------------------------------------
+    def upload_keyframe(self, slot, im, grad, theta, I_stddev, K, Tcw):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        assert im.shape == (self.H, self.W)
+        g, gp = _f32(grad)
+        t, tp = _f32(theta)
+        k, kp = _f32(K)
+        T, Tp = _f32(np.asarray(Tcw).reshape(12))
+        self._check(self.lib.sdm_upload_keyframe(self.ctx, slot, im.ctypes.data_as(_u8p), gp, tp,
+                                                 float(I_stddev), kp, Tp))
+
+    def upload_image(self, slot, im, K, Tcw):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        assert im.shape == (self.H, self.W)
+        k, kp = _f32(K)
+        T, Tp = _f32(np.asarray(Tcw).reshape(12))
+        self._check(self.lib.sdm_upload_image(self.ctx, slot, im.ctypes.data_as(_u8p), kp, Tp))
+
+    def upload_image_device(self, slot, dev_ptr, K, Tcw):
+        k, kp = _f32(K)
+        T, Tp = _f32(np.asarray(Tcw).reshape(12))
+        self._check(self.lib.sdm_upload_image_device(self.ctx, slot, dev_ptr, kp, Tp))
+
+    def set_pose(self, slot, Tcw):
+        T, Tp = _f32(np.asarray(Tcw).reshape(12))
+        self._check(self.lib.sdm_set_pose(self.ctx, slot, Tp))
+
+    def download_inputs(self, slot):
+        im = np.empty((self.H, self.W), np.uint8)
+        g = np.empty((self.H, self.W), np.float32)
+        t = np.empty((self.H, self.W), np.float32)
+        s = C.c_float()
+        self._check(self.lib.sdm_download_inputs(self.ctx, slot, im.ctypes.data_as(_u8p),
+                                                 g.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p),
+                                                 C.byref(s)))
+        return im, g, t, float(s.value)
+
+    # -- stages ------------------------------------------------------------------------------------
+    def _batch_args(self, refs, nbrs, rot, min_depth, max_depth):
+        refs = np.ascontiguousarray(refs, dtype=np.int32).reshape(-1)
+        n_ref = len(refs)
+        nbrs = np.ascontiguousarray(nbrs, dtype=np.int32).reshape(n_ref, -1)
+        n = nbrs.shape[1]
+        rot_a = None if rot is None else np.ascontiguousarray(rot, dtype=np.float32).reshape(n_ref, n)
+        mn = np.ascontiguousarray(np.broadcast_to(np.asarray(min_depth, np.float32), (n_ref,)))
+        mx = np.ascontiguousarray(np.broadcast_to(np.asarray(max_depth, np.float32), (n_ref,)))
+        return refs, n_ref, nbrs, n, rot_a, mn, mx
+
+    def _stage(self, fn, refs, nbrs, rot, min_depth, max_depth):
+        refs, n_ref, nbrs, n, rot_a, mn, mx = self._batch_args(refs, nbrs, rot, min_depth, max_depth)
+        self._check(fn(self.ctx, n_ref, refs.ctypes.data_as(_ip), n, nbrs.ctypes.data_as(_ip),
+                       None if rot_a is None else rot_a.ctypes.data_as(_f32p),
+                       mn.ctypes.data_as(_f32p), mx.ctypes.data_as(_f32p)))
+
+    def search_fuse(self, refs, nbrs, min_depth, max_depth, rot=None):
+        self._stage(self.lib.sdm_search_fuse, refs, nbrs, rot, min_depth, max_depth)
+
+    def recon(self, refs, nbrs, min_depth, max_depth, rot=None):
+        """SemiDenseRecon (PM.h:75) for a batch of reference keyframes."""
+        self._stage(self.lib.sdm_recon, refs, nbrs, rot, min_depth, max_depth)
+
+    def intra_check(self, refs):
+        r, rp = _i32(np.asarray(refs).reshape(-1))
+        self._check(self.lib.sdm_intra_check(self.ctx, len(r), rp))
+
+    def intra_grow(self, refs):
+        r, rp = _i32(np.asarray(refs).reshape(-1))
+        self._check(self.lib.sdm_intra_grow(self.ctx, len(r), rp))
+
+    def inter_check(self, refs, nbrs, commit=False):
+        refs = np.ascontiguousarray(refs, dtype=np.int32).reshape(-1)
+        nbrs = np.ascontiguousarray(nbrs, dtype=np.int32).reshape(len(refs), -1)
+        self._check(self.lib.sdm_inter_check(self.ctx, len(refs), refs.ctypes.data_as(_ip), nbrs.shape[1],
+                                             nbrs.ctypes.data_as(_ip), 1 if commit else 0))
+
+    def pointset(self, refs, source=1):
+        r, rp = _i32(np.asarray(refs).reshape(-1))
+        self._check(self.lib.sdm_pointset(self.ctx, len(r), rp, source))
+
+    # -- maps ---------------------------------------------------------------------------------------
+    def upload_depth(self, slot, rho, sigma):
+        r, rp = _f32(rho)
+        s, sp = _f32(sigma)
+        assert r.shape == (self.H, self.W) and s.shape == (self.H, self.W)
+        self._check(self.lib.sdm_upload_depth(self.ctx, slot, rp, sp))
+
+    def download_depth(self, slot):
+        r = np.empty((self.H, self.W), np.float32)
+        s = np.empty((self.H, self.W), np.float32)
+        self._check(self.lib.sdm_download_depth(self.ctx, slot, r.ctypes.data_as(_f32p), s.ctypes.data_as(_f32p)))
+        return r, s
+
+    def download_checked(self, slot):
+        r = np.empty((self.H, self.W), np.float32)
+        self._check(self.lib.sdm_download_checked(self.ctx, slot, r.ctypes.data_as(_f32p)))
+        return r
+
+    def download_pointset(self, slot):
+        x = np.empty((self.H, 3 * self.W), np.float32)
+        self._check(self.lib.sdm_download_pointset(self.ctx, slot, x.ctypes.data_as(_f32p)))
+        return x
+
+    def intra_check_maps(self, rho, sigma, grad=None):
+        r = np.array(rho, dtype=np.float32, order="C")
+        s = np.array(sigma, dtype=np.float32, order="C")
+        gp = None
+        if grad is not None:
+            g, gp = _f32(grad)
+        self._check(self.lib.sdm_intra_check_maps(self.ctx, r.ctypes.data_as(_f32p), s.ctypes.data_as(_f32p), gp))
+        return r, s
+
+    def intra_grow_maps(self, rho, sigma, grad):
+        r = np.array(rho, dtype=np.float32, order="C")
+        s = np.array(sigma, dtype=np.float32, order="C")
+        g, gp = _f32(grad)
+        self._check(self.lib.sdm_intra_grow_maps(self.ctx, r.ctypes.data_as(_f32p), s.ctypes.data_as(_f32p), gp))
+        return r, s
+
+    # -- per-pixel ------------------------------------------------------------------------------------
+    def epipolar_search(self, ref, nbr, x, y, min_depth, max_depth, rot=0.0):
+        out = (C.c_float * 5)()
+        self._check(self.lib.sdm_epipolar_search(self.ctx, ref, nbr, x, y, min_depth, max_depth, rot, out))
+        return dict(rho=float(out[0]), sigma=float(out[1]), supported=int(out[2]), best_u=float(out[3]),
+                    best_v=float(out[4]))
+
+    def search_range(self, ref, nbr, x, y, mind, maxd):
+        a, b = C.c_float(), C.c_float()
+        self._check(self.lib.sdm_search_range(self.ctx, ref, nbr, x, y, mind, maxd, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def fuse(self, rho, sigma):
+        r, rp = _f32(rho)
+        s, sp = _f32(sigma)
+        out = (C.c_float * 3)()
+        self._check(self.lib.sdm_fuse(self.ctx, rp, sp, len(r), out))
+        return float(out[0]), float(out[1]), int(out[2])
+
+    def pair_geometry(self, ref, nbr):
+        F = np.empty(9, np.float32)
+        R = np.empty(9, np.float32)
+        t = np.empty(3, np.float32)
+        self._check(self.lib.sdm_pair_geometry(self.ctx, ref, nbr, F.ctypes.data_as(_f32p),
+                                               R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p)))
+        return F, R, t
+
+    # -- instrumentation ---------------------------------------------------------------------------------
+    def enable_stats(self, on=True):
+        self._check(self.lib.sdm_enable_stats(self.ctx, 1 if on else 0))
+
+    STAGES = ("search_fuse", "intra", "inter", "pointset")
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.sdm_enable_timing(self.ctx, 1 if on else 0))
+
+    def get_timing(self, reset=True):
+        """{stage: (total_ms, launches)} from HIP events on the engine's stream"""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_longlong * 4)()
+        self._check(self.lib.sdm_get_timing(self.ctx, ms, cnt, 1 if reset else 0))
+        return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(self.STAGES)}
+
+    def get_stats(self, reset=True):
+        s = Stats()
+        self._check(self.lib.sdm_get_stats(self.ctx, C.byref(s), 1 if reset else 0))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}

@@ -1,0 +1,366 @@
+// sdm_device.h -- device-side arithmetic of the ProbabilityMapping path for gfx950.
+//
+// Every function here is the GPU statement of a piece of
+// /root/reference/src/Modeler/ProbabilityMapping.cc ("PM.cc"); the cited lines give the float /
+// double promotion pattern that must be kept for the support masks to stay bit-exact
+// (SURVEY.md App. A.0).  Built with -ffp-contract=off: no mul-add may be fused, and hipcc's
+// default correctly-rounded f32 divide/sqrt is relied upon.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "sdm_c.h"
+
+namespace sdm {
+
+// ---- device-resident tables ------------------------------------------------------------------
+struct KfMeta {  // per keyframe slot; what PM.cc reads through KeyFrame accessors
+    float fx, fy, cx, cy;  // include/KeyFrame.h:162
+    float Tcw[12];         // src/KeyFrame.cc:70-121
+    float I_stddev;        // PM.cc:457
+    int uploaded;
+    int pad[2];
+};
+
+struct RefConst {  // per reference keyframe of a batch
+    int slot;
+    float fx, fy, cx, cy;
+    float mind, maxd;  // min_depth / max_depth as named at PM.cc:381-382
+    int pad;
+};
+
+struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of the per-pixel code
+    float F[9];                 // F12, PM.cc:972-986
+    float R[9];                 // R21, PM.cc:859 == 890 == 643
+    float t[3];                 // t21, PM.cc:860 == 891 == 644
+    float rot;                  // median in-plane rotation, PM.cc:170-179
+    float istd;                 // neighbour's I_stddev, PM.cc:457
+    int nbr_slot;
+    float nfx, nfy, ncx, ncy;  // neighbour intrinsics, PM.cc:675
+    float pad[4];
+};
+static_assert(sizeof(PairConst) == 128, "PairConst must stay 128 B");
+
+struct DevParams {  // sdm_params + host-precomputed (1/THETA), PM.cc:455-456
+    float lambdaG, lambdaL, lambdaTheta;
+    int lambdaN;
+    double theta_var;
+    double inv_theta;
+};
+
+// ---- cv::fastAtan2 (PM.cc:414): OpenCV 3.x atan_f32 polynomial, degrees [0,360) ------------------
+__host__ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ---- 3x3 float algebra, left-to-right accumulation ----------------------------------------------
+__host__ __device__ inline void mat3_mul(const float* A, const float* B, float* C)
+{
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) {
+            float p0 = A[i * 3 + 0] * B[0 * 3 + k];
+            float p1 = A[i * 3 + 1] * B[1 * 3 + k];
+            float p2 = A[i * 3 + 2] * B[2 * 3 + k];
+            C[i * 3 + k] = (p0 + p1) + p2;
+        }
+}
+__host__ __device__ inline void mat3_mul_bt(const float* A, const float* B, float* C)
+{
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) {
+            float p0 = A[i * 3 + 0] * B[k * 3 + 0];
+            float p1 = A[i * 3 + 1] * B[k * 3 + 1];
+            float p2 = A[i * 3 + 2] * B[k * 3 + 2];
+            C[i * 3 + k] = (p0 + p1) + p2;
+        }
+}
+__host__ __device__ inline void mat3_vec(const float* A, const float* v, float* o)
+{
+    for (int i = 0; i < 3; i++) {
+        float p0 = A[i * 3 + 0] * v[0];
+        float p1 = A[i * 3 + 1] * v[1];
+        float p2 = A[i * 3 + 2] * v[2];
+        o[i] = (p0 + p1) + p2;
+    }
+}
+
+// R21/t21 (PM.cc:859-860) and F12 (PM.cc:972-986; skew matrix as src/LocalMapping.cc:711-716,
+// since PM's GetSkewSymmetricMatrix is declared but never defined).  K^-1 in closed form.
+__host__ __device__ inline void pair_geometry(const KfMeta& k1, const KfMeta& k2, float* F12,
+                                              float* R21, float* t21)
+{
+    float R1[9], t1[3], R2[9], t2[3], tmp[3];
+    for (int i = 0; i < 3; i++) {
+        for (int k = 0; k < 3; k++) {
+            R1[i * 3 + k] = k1.Tcw[i * 4 + k];
+            R2[i * 3 + k] = k2.Tcw[i * 4 + k];
+        }
+        t1[i] = k1.Tcw[i * 4 + 3];
+        t2[i] = k2.Tcw[i * 4 + 3];
+    }
+    mat3_mul_bt(R2, R1, R21);
+    mat3_vec(R21, t1, tmp);
+    for (int i = 0; i < 3; i++) t21[i] = (-tmp[i]) + t2[i];
+
+    float R12[9], t12[3];
+    mat3_mul_bt(R1, R2, R12);
+    mat3_vec(R12, t2, tmp);
+    for (int i = 0; i < 3; i++) t12[i] = (-tmp[i]) + t1[i];
+
+    float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
+    float K1ti[9] = {1.0f / k1.fx, 0.f, 0.f, 0.f, 1.0f / k1.fy, 0.f,
+                     -k1.cx / k1.fx, -k1.cy / k1.fy, 1.f};
+    float K2i[9] = {1.0f / k2.fx, 0.f, -k2.cx / k2.fx, 0.f, 1.0f / k2.fy, -k2.cy / k2.fy,
+                    0.f, 0.f, 1.f};
+    float A[9], B[9];
+    mat3_mul(K1ti, t12x, A);
+    mat3_mul(A, R12, B);
+    mat3_mul(B, K2i, F12);
+}
+
+// R21.row(i) * xp, xp = (xp0, xp1, 1): PM.cc:866,868,894
+__device__ __forceinline__ float row_dot_xp(const float* r, float xp0, float xp1)
+{
+    float p0 = r[0] * xp0;
+    float p1 = r[1] * xp1;
+    float p2 = r[2] * 1.0f;
+    return (p0 + p1) + p2;
+}
+
+// ---- search record: everything one scan candidate needs in ONE 16-byte load ----------------------
+//   .x = GradImg(y,x)   .y = GradTheta(y,x)   .z = GradImg(y+1,x)
+//   .w = bits: im(y,x) | im(y+1,x) << 8
+// bilinear<T>(img, yf, uj) of PM.cc:40-59 at integer uj only ever touches rows floor(yf) and
+// floor(yf)+1 of column uj, which is exactly one record.
+__device__ __forceinline__ float rec_lerp_im(const float4& r, int y0, float yf)
+{
+    unsigned w = __float_as_uint(r.w);
+    float y0w = (float)(y0 + 1) - yf;
+    float y1w = 1.0f - y0w;
+    float v0 = (float)(int)(w & 0xffu), v1 = (float)(int)((w >> 8) & 0xffu);
+    return v0 * y0w + v1 * y1w;
+}
+__device__ __forceinline__ float rec_lerp_grad(const float4& r, int y0, float yf)
+{
+    float y0w = (float)(y0 + 1) - yf;
+    float y1w = 1.0f - y0w;
+    return r.x * y0w + r.z * y1w;
+}
+
+// GetPixelDepth, PM.cc:845-875 (Eq. 8) with the per-(pixel,pair) dot products hoisted.
+__device__ __forceinline__ float pixel_depth(float uj, float fx, float cx, float rzxp, float rxxp,
+                                             float tx, float tz)
+{
+    float ucx = uj - cx;
+    float num1 = rzxp * ucx;
+    float num2 = fx * rxxp;
+    float denom1 = -tz * ucx;
+    float denom2 = fx * tx;
+    return (num1 - num2) / (denom1 + denom2);
+}
+
+// GetSearchRange, PM.cc:877-910
+__device__ __forceinline__ void search_range(float fx, float cx, float rxxp, float rzxp, float tx,
+                                             float tz, float mind, float maxd, int W, float& umin,
+                                             float& umax)
+{
+    float x_min = rxxp * mind + tx, z_min = rzxp * mind + tz;
+    float x_max = rxxp * maxd + tx, z_max = rzxp * maxd + tz;
+    umin = fx * x_min / z_min + cx;
+    umax = fx * x_max / z_max + cx;
+    if (umin > umax) {
+        float t = umax;
+        umax = umin;
+        umin = t;
+    }
+    float cols = (float)W;
+    if (umin < 0) umin = 0;
+    if (umax < 0) umax = 0;
+    if (umin > cols) umin = cols;
+    if (umax > cols) umax = cols;
+}
+
+struct SearchStats {
+    unsigned long long searches, candidates, gate_pass;
+};
+
+// EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
+// nrec: the neighbour keyframe's record plane.  Returns true iff a hypothesis was produced
+// (dh.supported).  Normative deviations N3-N5 as in oracle/pm_oracle.c / DESIGN.md §3.
+template <bool STATS>
+__device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
+                                                const PairConst* __restrict__ pc, float fx,
+                                                float cx, int x, int y, float pixel, float grad1,
+                                                float th_pi, float xp0, float xp1, float mind,
+                                                float maxd, const DevParams& prm, float& rho_o,
+                                                float& sigma_o, float& best_u, float& best_v,
+                                                SearchStats* st)
+{
+    rho_o = 0.f;
+    sigma_o = 0.f;
+    best_u = 0.f;
+    best_v = 0.f;
+    if (STATS) st->searches++;
+    const float* F = pc->F;
+    float a = (float)x * F[0] + (float)y * F[3] + F[6];  // PM.cc:389-391
+    float b = (float)x * F[1] + (float)y * F[4] + F[7];
+    float c = (float)x * F[2] + (float)y * F[5] + F[8];
+    float ab = a / b;
+    if (ab < -4 || ab > 4) return false;  // PM.cc:393
+    if (ab != ab) return false;
+    float cb = c / b;
+
+    float rxxp = row_dot_xp(pc->R + 0, xp0, xp1);
+    float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+    float tx = pc->t[0], tz = pc->t[2];
+    float umin, umax;
+    search_range(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, umin, umax);  // PM.cc:404
+    if (umin != umin || umax != umax) return false;
+
+    float th_line = fast_atan2_deg(-a / b, 1.0f);  // PM.cc:414 (loop invariant)
+    float ang_pi_rot = th_pi + pc->rot;            // PM.cc:424-426
+    if (ang_pi_rot >= 360) ang_pi_rot -= 360;
+    if (ang_pi_rot < 0) ang_pi_rot += 360;
+
+    float old_err = 1000000.0f;
+    float best_pe = 0.f, best_ge = 0.f;
+    int best_pixel = 0;
+    int lo = (int)ceilf(umin);
+    int hi = (int)floorf(umax);
+    if (hi > W - 1) hi = W - 1;
+    const float hlim = (float)(H - 1);
+    for (int uj = lo; uj <= hi; uj++) {  // PM.cc:405
+        if (STATS) st->candidates++;
+        float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
+        if (!(yf >= 1.0f && yf < hlim)) continue;
+        int vj = (int)yf;
+        float4 r = nrec[vj * W + uj];
+        if (r.x < prm.lambdaG) continue;  // PM.cc:411
+        float ang_diff = r.y - th_line;   // PM.cc:415-421
+        if (ang_diff >= 360) ang_diff -= 360;
+        if (ang_diff < 0) ang_diff += 360;
+        if (ang_diff > 180) ang_diff = 360 - ang_diff;
+        if (ang_diff > 90) ang_diff = 180 - ang_diff;
+        if (ang_diff > prm.lambdaL) continue;
+        float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
+        if (th_diff >= 360) th_diff -= 360;
+        if (th_diff < 0) th_diff += 360;
+        if (th_diff > 180) th_diff = 360 - th_diff;
+        if (th_diff > prm.lambdaTheta) continue;
+        if (STATS) st->gate_pass++;
+        float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
+        float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
+        float pe2 = pe * pe, ge2 = ge * ge;
+        float err = (float)((double)pe2 + (double)ge2 / prm.theta_var);  // PM.cc:436
+        if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
+            best_pixel = uj;
+            old_err = err;
+            best_pe = pe;
+            best_ge = ge;
+        }
+    }
+    if (!(old_err < 1000000.0f)) return false;  // PM.cc:446
+
+    int up = best_pixel + 1, um = best_pixel - 1;  // PM.cc:449-450
+    if (um < 0 || up > W - 1) return false;
+    float yfp = -(ab * (float)up + cb);
+    float yfm = -(ab * (float)um + cb);
+    float fyp = floorf(yfp), fym = floorf(yfm);
+    const float hlim2 = (float)(H - 2);
+    if (!(fyp >= 0.0f && fyp <= hlim2)) return false;
+    if (!(fym >= 0.0f && fym <= hlim2)) return false;
+    int y0p = (int)fyp, y0m = (int)fym;
+    float4 rp = nrec[y0p * W + up];
+    float4 rm = nrec[y0m * W + um];
+    float g = (rec_lerp_im(rp, y0p, yfp) - rec_lerp_im(rm, y0m, yfm)) / 2;      // PM.cc:452
+    float q = (rec_lerp_grad(rp, y0p, yfp) - rec_lerp_grad(rm, y0m, yfm)) / 2;  // PM.cc:453
+    const double inv_theta = prm.inv_theta;
+    float gg = g * g;
+    float denom = (float)((double)gg + inv_theta * (double)q * (double)q);  // PM.cc:455
+    float gpe = g * best_pe;
+    float ustar = (float)((double)best_pixel +
+                          ((double)gpe + inv_theta * (double)q * (double)best_ge) / (double)denom);
+    float ustar_var = 2 * pc->istd * pc->istd / denom;  // PM.cc:457
+    best_u = ustar;
+    best_v = -(ab * ustar + cb);  // PM.cc:460
+
+    // ComputeInvDepthHypothesis PM.cc:806-829
+    float d0 = pixel_depth(ustar, fx, cx, rzxp, rxxp, tx, tz);
+    float s = sqrtf(ustar_var);
+    float dmin = pixel_depth(ustar - s, fx, cx, rzxp, rxxp, tx, tz);
+    float dmax = pixel_depth(ustar + s, fx, cx, rzxp, rxxp, tx, tz);
+    float e1 = fabsf(dmax - d0), e2 = fabsf(dmin - d0);
+    rho_o = d0;
+    sigma_o = (e1 < e2) ? e2 : e1;  // cv::max(a,b) = (a<b)?b:a
+    return true;
+}
+
+// ChiTest, PM.cc:912-924 (both overloads share this arithmetic)
+__device__ __forceinline__ bool chi_test(float a, float b, float sa, float sb)
+{
+    float d = a - b;
+    float num = d * d;
+    float chi = num / (sa * sa) + num / (sb * sb);
+    return (double)chi < 5.99;
+}
+
+// one term of GetFusion (PM.cc:936-937 / 956-957): pow(sigma,2) is double, the sums are float
+__device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, float& rsj)
+{
+    double s2 = (double)sg * (double)sg;
+    pjsj = (float)((double)pjsj + (double)rho / s2);
+    rsj = (float)((double)rsj + 1.0 / s2);
+}
+
+// InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.
+__device__ __forceinline__ bool fuse_column(const float2* hyp, int stride, int nh, int lambdaN,
+                                            float& rho_o, float& sigma_o)
+{
+    unsigned long long bestmask = 0;
+    int best = 0;
+    for (int a = 0; a < nh; a++) {
+        float2 ha = hyp[a * stride];
+        unsigned long long m = 0;
+        for (int b = 0; b < nh; b++) {
+            float2 hb = hyp[b * stride];
+            if (chi_test(ha.x, hb.x, ha.y, hb.y)) m |= 1ull << b;
+        }
+        int cnt = __popcll(m);
+        if (cnt > best) {  // strict: first largest set wins, PM.cc:616
+            best = cnt;
+            bestmask = m;
+        }
+    }
+    if (best < lambdaN) return false;  // PM.cc:623
+    float pjsj = 0.f, rsj = 0.f;       // GetFusion overload B, PM.cc:947-970
+    for (int b = 0; b < nh; b++) {
+        if (!((bestmask >> b) & 1ull)) continue;
+        float2 hb = hyp[b * stride];
+        fusion_accum(hb.x, hb.y, pjsj, rsj);
+    }
+    rho_o = pjsj / rsj;
+    sigma_o = sqrtf(1 / rsj);
+    return true;
+}
+
+}  // namespace sdm

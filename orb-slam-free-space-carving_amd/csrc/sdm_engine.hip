@@ -1,0 +1,955 @@
+// sdm_engine.hip -- context, memory pools and the C ABI (include/sdm_c.h) of libsdm_hip.so.
+//
+// Data layout in HBM (per keyframe slot, P = W*H pixels):
+//   rec   float4[P]   16 B/px  search records {grad, theta, grad(y+1), im|im(y+1)<<8}   (inputs)
+//   pool  float2[P]    8 B/px  depth map {rho, sigma}  = kf->depth_map_/depth_sigma_     (K1-K3)
+//   chk   float [P]    4 B/px  inter-keyframe-checked rho                                 (K4)
+//   xyz   float [3P]  12 B/px  SemiDensePointSets_ (optional)                             (K5)
+// plus one scratch pool of batch_capacity slots for the Jacobi stencil passes (K2 writes scratch,
+// K3 writes back), one staging keyframe for uploads, and the per-batch constant tables.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdm_c.h"
+#include "sdm_kernels.h"
+
+using namespace sdm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(SDM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    } while (0)
+
+}  // namespace
+
+struct sdm_ctx {
+    sdm_config cfg{};
+    int W = 0, H = 0;
+    long long P = 0;
+    TileGeom geom{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string arch;
+
+    float4* rec = nullptr;
+    float2* pool = nullptr;
+    bool own_pool = false;
+    float2* scratch = nullptr;
+    float* chk = nullptr;
+    float* xyz = nullptr;
+    KfMeta* d_meta = nullptr;
+    std::vector<KfMeta> h_meta;
+    std::vector<char> has_depth, has_chk;
+
+    // staging for one keyframe
+    uint8_t* d_im = nullptr;
+    float* d_grad = nullptr;
+    float* d_theta = nullptr;
+    unsigned long long* d_sums = nullptr;
+    float* d_small = nullptr;  // 16 floats of per-pixel results
+
+    // per-call tables (device + pinned host mirrors)
+    int cap_refs = 0;
+    int *d_ref_slots = nullptr, *h_ref_slots = nullptr;
+    int *d_nbr_slots = nullptr, *h_nbr_slots = nullptr;
+    float *d_rot = nullptr, *h_rot = nullptr;
+    float *d_mind = nullptr, *h_mind = nullptr;
+    float *d_maxd = nullptr, *h_maxd = nullptr;
+    long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of cap_refs
+    RefConst* d_refs = nullptr;
+    PairConst* d_pairs = nullptr;
+    hipEvent_t tables_free = nullptr;
+    bool tables_pending = false;
+
+    float2* h_f2 = nullptr;  // pinned interleave buffer, P elements
+
+    sdm_params prm{};
+    DevParams dprm{};
+    bool stats_on = false;
+    unsigned long long* d_stats = nullptr;
+
+    // optional per-stage HIP-event timing (sdm_enable_timing)
+    struct Span {
+        hipEvent_t a, b;
+        int stage;
+    };
+    bool timing_on = false;
+    std::vector<Span> spans;
+    size_t spans_used = 0;
+};
+
+namespace {
+
+void set_dev_params(sdm_ctx* c)
+{
+    c->dprm.lambdaG = c->prm.lambdaG;
+    c->dprm.lambdaL = c->prm.lambdaL;
+    c->dprm.lambdaTheta = c->prm.lambdaTheta;
+    c->dprm.lambdaN = c->prm.lambdaN;
+    c->dprm.theta_var = c->prm.theta_var;
+    c->dprm.inv_theta = 1 / c->prm.theta_var;  // (1/THETA), PM.cc:455
+}
+
+int check_slot(sdm_ctx* c, int slot, bool need_upload)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (slot < 0 || slot >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "slot out of range");
+    if (need_upload && !c->h_meta[slot].uploaded) return fail(SDM_ESTATE, "slot has no keyframe uploaded");
+    return SDM_OK;
+}
+
+int wait_tables(sdm_ctx* c)
+{
+    if (c->tables_pending) {
+        HIP_TRY(hipEventSynchronize(c->tables_free));
+        c->tables_pending = false;
+    }
+    return SDM_OK;
+}
+
+int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+// HIP events around one stage's launches, on the stream the kernels run on
+struct StageTimer {
+    sdm_ctx* c;
+    sdm_ctx::Span* sp = nullptr;
+    StageTimer(sdm_ctx* ctx, int stage) : c(ctx)
+    {
+        if (!c->timing_on) return;
+        if (c->spans_used == c->spans.size()) {
+            if (c->spans.size() >= 65536) return;
+            sdm_ctx::Span n{};
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            c->spans.push_back(n);
+        }
+        sp = &c->spans[c->spans_used++];
+        sp->stage = stage;
+        (void)hipEventRecord(sp->a, c->stream);
+    }
+    ~StageTimer()
+    {
+        if (sp) (void)hipEventRecord(sp->b, c->stream);
+    }
+};
+
+// upload slot tables for a call; builds RefConst/PairConst on device when n > 0
+int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, const float* rot,
+                 const float* mind, const float* maxd)
+{
+    if (n_ref <= 0 || !ref_slots) return fail(SDM_EINVAL, "n_ref <= 0 or null ref_slots");
+    if (n_ref > c->cap_refs) return fail(SDM_EINVAL, "n_ref exceeds max_keyframes");
+    if (n < 0 || n > c->cfg.max_neighbours) return fail(SDM_EINVAL, "n exceeds max_neighbours");
+    if (n > 0 && !nbr_slots) return fail(SDM_EINVAL, "null nbr_slots");
+    for (int r = 0; r < n_ref; r++) {
+        int rc = check_slot(c, ref_slots[r], true);
+        if (rc) return rc;
+        for (int j = 0; j < n; j++) {
+            rc = check_slot(c, nbr_slots[r * n + j], true);
+            if (rc) return rc;
+        }
+    }
+    int rc = wait_tables(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    memcpy(c->h_ref_slots, ref_slots, sizeof(int) * n_ref);
+    HIP_TRY(hipMemcpyAsync(c->d_ref_slots, c->h_ref_slots, sizeof(int) * n_ref, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        size_t np = (size_t)n_ref * n;
+        memcpy(c->h_nbr_slots, nbr_slots, sizeof(int) * np);
+        if (rot)
+            memcpy(c->h_rot, rot, sizeof(float) * np);
+        else
+            memset(c->h_rot, 0, sizeof(float) * np);
+        for (int r = 0; r < n_ref; r++) {
+            c->h_mind[r] = mind ? mind[r] : 0.f;
+            c->h_maxd[r] = maxd ? maxd[r] : 0.f;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_nbr_slots, c->h_nbr_slots, sizeof(int) * np, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_rot, c->h_rot, sizeof(float) * np, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_mind, c->h_mind, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_maxd, c->h_maxd, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_pair_setup, dim3(blocks_for((long long)np)), dim3(BLOCK), 0, c->stream, c->d_meta,
+                           c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, n_ref, n, c->d_refs,
+                           c->d_pairs);
+        HIP_TRY(hipGetLastError());
+    }
+    return SDM_OK;
+}
+
+int tables_staged(sdm_ctx* c)
+{
+    HIP_TRY(hipEventRecord(c->tables_free, c->stream));
+    c->tables_pending = true;
+    return SDM_OK;
+}
+
+int push_meta(sdm_ctx* c, int slot)
+{
+    HIP_TRY(hipMemcpyAsync(c->d_meta + slot, &c->h_meta[slot], sizeof(KfMeta), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+void fill_meta(KfMeta& m, const float K[4], const float Tcw[12])
+{
+    m.fx = K[0];
+    m.fy = K[1];
+    m.cx = K[2];
+    m.cy = K[3];
+    memcpy(m.Tcw, Tcw, sizeof(float) * 12);
+}
+
+int pack_staged(sdm_ctx* c, int slot)
+{
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->d_im, c->d_grad, c->d_theta,
+                       c->W, c->H, c->rec + (long long)slot * c->P);
+    HIP_TRY(hipGetLastError());
+    return SDM_OK;
+}
+
+// gradient pre-pass from c->d_im (or an external device image) into the staging planes + records
+int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
+{
+    HIP_TRY(hipMemsetAsync(c->d_sums, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_gradient, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->W, c->H, c->d_grad,
+                       c->d_theta, c->d_sums);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_istd_finish, dim3(1), dim3(1), 0, c->stream, c->d_sums, c->W, c->H, c->d_meta + slot);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->d_grad, c->d_theta,
+                       c->W, c->H, c->rec + (long long)slot * c->P);
+    HIP_TRY(hipGetLastError());
+    // mirror the derived I_stddev on the host
+    HIP_TRY(hipMemcpyAsync(&c->h_meta[slot].I_stddev, &c->d_meta[slot].I_stddev, sizeof(float), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t count)
+{
+    HIP_TRY(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1)));
+    return SDM_OK;
+}
+template <typename T>
+int host_alloc(T** p, size_t count)
+{
+    HIP_TRY(hipHostMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1), hipHostMallocDefault));
+    return SDM_OK;
+}
+
+size_t search_lds_bytes(int n) { return sizeof(float2) * (size_t)BLOCK * (size_t)std::max(n, 1); }
+
+}  // namespace
+
+extern "C" {
+
+void sdm_default_params(sdm_params* p)
+{
+    p->lambdaG = 8.0f;
+    p->lambdaL = 80.0f;
+    p->lambdaTheta = 45.0f;
+    p->lambdaN = 3;
+    p->theta_var = 0.23;
+}
+
+void sdm_default_config(sdm_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->W = 640;
+    c->H = 480;
+    c->max_keyframes = 16;
+    c->max_neighbours = 7;  // covisN, PM.h:38
+    c->with_pointset = 1;
+}
+
+size_t sdm_depth_pool_bytes(int W, int H, int max_keyframes)
+{
+    return sizeof(float2) * (size_t)W * (size_t)H * (size_t)max_keyframes;
+}
+
+const char* sdm_last_error(void) { return g_err.c_str(); }
+
+int sdm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sdm_create(sdm_ctx** out, const sdm_config* cfg)
+{
+    if (!out || !cfg) return fail(SDM_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->W < 8 || cfg->H < 8 || cfg->W > 16384 || cfg->H > 16384) return fail(SDM_EINVAL, "bad image size");
+    if ((long long)cfg->W * cfg->H >= (1ll << 31) / 4) return fail(SDM_EINVAL, "image too large");
+    if (cfg->max_keyframes < 1) return fail(SDM_EINVAL, "max_keyframes < 1");
+    if (cfg->max_neighbours < 1 || cfg->max_neighbours > SDM_MAX_NEIGHBOURS)
+        return fail(SDM_EINVAL, "max_neighbours out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SDM_ENODEV, "no HIP device visible: this engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SDM_EINVAL, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+
+    sdm_ctx* c = new sdm_ctx();
+    c->cfg = *cfg;
+    c->arch = prop.gcnArchName;
+    c->W = cfg->W;
+    c->H = cfg->H;
+    c->P = (long long)cfg->W * cfg->H;
+    c->geom = make_geom(cfg->W, cfg->H);
+    if (c->cfg.batch_capacity <= 0) c->cfg.batch_capacity = std::min(cfg->max_keyframes, 64);
+    c->cfg.batch_capacity = std::max(2, std::min(c->cfg.batch_capacity, std::max(cfg->max_keyframes, 2)));
+    sdm_default_params(&c->prm);
+    set_dev_params(c);
+    const int K = cfg->max_keyframes;
+    c->cap_refs = K;
+    c->h_meta.assign(K, KfMeta{});
+    c->has_depth.assign(K, 0);
+    c->has_chk.assign(K, 0);
+
+    int rc = SDM_OK;
+    auto bail = [&](int code) {
+        std::string keep = g_err;
+        sdm_destroy(c);
+        g_err = keep;
+        return code;
+    };
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
+        c->own_stream = true;
+    }
+    if ((rc = dev_alloc(&c->rec, (size_t)c->P * K))) return bail(rc);
+    if (cfg->ext_depth_pool) {
+        c->pool = (float2*)cfg->ext_depth_pool;
+    } else {
+        if ((rc = dev_alloc(&c->pool, (size_t)c->P * K))) return bail(rc);
+        c->own_pool = true;
+    }
+    if ((rc = dev_alloc(&c->scratch, (size_t)c->P * c->cfg.batch_capacity))) return bail(rc);
+    if ((rc = dev_alloc(&c->chk, (size_t)c->P * K))) return bail(rc);
+    if (cfg->with_pointset)
+        if ((rc = dev_alloc(&c->xyz, (size_t)c->P * 3 * K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_meta, (size_t)K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_sums, 2))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_small, 16))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
+    const size_t np = (size_t)K * cfg->max_neighbours;
+    if ((rc = dev_alloc(&c->d_ref_slots, K)) || (rc = host_alloc(&c->h_ref_slots, K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_nbr_slots, np)) || (rc = host_alloc(&c->h_nbr_slots, np))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_rot, np)) || (rc = host_alloc(&c->h_rot, np))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_mind, K)) || (rc = host_alloc(&c->h_mind, K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_maxd, K)) || (rc = host_alloc(&c->h_maxd, K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_off, (size_t)3 * K)) || (rc = host_alloc(&c->h_off, (size_t)3 * K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_refs, K)) || (rc = dev_alloc(&c->d_pairs, np))) return bail(rc);
+    if ((rc = host_alloc(&c->h_f2, (size_t)c->P))) return bail(rc);
+    if (hipEventCreateWithFlags(&c->tables_free, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+
+    // zero-initialised maps, as a fresh KeyFrame's depth_map_/depth_sigma_/SemiDensePointSets_
+    if (hipMemsetAsync(c->rec, 0, sizeof(float4) * c->P * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->pool, 0, sizeof(float2) * c->P * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->chk, 0, sizeof(float) * c->P * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_meta, 0, sizeof(KfMeta) * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
+        (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return bail(fail(SDM_EHIP, "initial memset failed"));
+
+    // K1's hypothesis columns can need more than the default 64 KB of dynamic LDS
+    const int max_lds = (int)search_lds_bytes(cfg->max_neighbours);
+    if (hipFuncSetAttribute((const void*)k_search_fuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)k_search_fuse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
+            hipSuccess)
+        return bail(fail(SDM_EHIP, "hipFuncSetAttribute(max dynamic LDS) failed"));
+    *out = c;
+    return SDM_OK;
+}
+
+void sdm_destroy(sdm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->rec);
+    if (c->own_pool) (void)hipFree(c->pool);
+    (void)hipFree(c->scratch);
+    (void)hipFree(c->chk);
+    (void)hipFree(c->xyz);
+    (void)hipFree(c->d_meta);
+    (void)hipFree(c->d_im);
+    (void)hipFree(c->d_grad);
+    (void)hipFree(c->d_theta);
+    (void)hipFree(c->d_sums);
+    (void)hipFree(c->d_small);
+    (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_ref_slots);
+    (void)hipFree(c->d_nbr_slots);
+    (void)hipFree(c->d_rot);
+    (void)hipFree(c->d_mind);
+    (void)hipFree(c->d_maxd);
+    (void)hipFree(c->d_off);
+    (void)hipFree(c->d_refs);
+    (void)hipFree(c->d_pairs);
+    (void)hipHostFree(c->h_ref_slots);
+    (void)hipHostFree(c->h_nbr_slots);
+    (void)hipHostFree(c->h_rot);
+    (void)hipHostFree(c->h_mind);
+    (void)hipHostFree(c->h_maxd);
+    (void)hipHostFree(c->h_off);
+    (void)hipHostFree(c->h_f2);
+    if (c->tables_free) (void)hipEventDestroy(c->tables_free);
+    for (auto& sp : c->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sdm_set_params(sdm_ctx* c, const sdm_params* p)
+{
+    if (!c || !p) return fail(SDM_EINVAL, "null argument");
+    if (!(p->theta_var > 0) || p->lambdaN < 0) return fail(SDM_EINVAL, "bad parameter value");
+    c->prm = *p;
+    set_dev_params(c);
+    return SDM_OK;
+}
+
+int sdm_set_stream(sdm_ctx* c, void* s)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) {
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    c->stream = (hipStream_t)s;
+    return SDM_OK;
+}
+
+int sdm_synchronize(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+const char* sdm_device_arch(sdm_ctx* c) { return c ? c->arch.c_str() : ""; }
+
+// ---- keyframe inputs -----------------------------------------------------------------------------------------
+int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* grad, const float* theta, float I_stddev,
+                        const float K[4], const float Tcw[12])
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!im || !grad || !theta || !K || !Tcw) return fail(SDM_EINVAL, "null input plane");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->d_im, im, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_grad, grad, sizeof(float) * c->P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_theta, theta, sizeof(float) * c->P, hipMemcpyHostToDevice, c->stream));
+    if ((rc = pack_staged(c, slot))) return rc;
+    KfMeta& m = c->h_meta[slot];
+    fill_meta(m, K, Tcw);
+    m.I_stddev = I_stddev;
+    m.uploaded = 1;
+    return push_meta(c, slot);
+}
+
+int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], const float Tcw[12])
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->d_im, im, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    KfMeta& m = c->h_meta[slot];
+    fill_meta(m, K, Tcw);
+    m.uploaded = 1;
+    if ((rc = push_meta(c, slot))) return rc;
+    return prepass_and_pack(c, slot, c->d_im);
+}
+
+int sdm_upload_image_device(sdm_ctx* c, int slot, const void* d_im, const float K[4], const float Tcw[12])
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!d_im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    KfMeta& m = c->h_meta[slot];
+    fill_meta(m, K, Tcw);
+    m.uploaded = 1;
+    if ((rc = push_meta(c, slot))) return rc;
+    return prepass_and_pack(c, slot, (const uint8_t*)d_im);
+}
+
+int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!Tcw) return fail(SDM_EINVAL, "null pose");
+    memcpy(c->h_meta[slot].Tcw, Tcw, sizeof(float) * 12);
+    return push_meta(c, slot);
+}
+
+int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* theta, float* I_stddev)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(k_unpack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->rec + (long long)slot * c->P,
+                       (int)c->P, c->d_im, c->d_grad, c->d_theta);
+    HIP_TRY(hipGetLastError());
+    if (im) HIP_TRY(hipMemcpyAsync(im, c->d_im, (size_t)c->P, hipMemcpyDeviceToHost, c->stream));
+    if (grad) HIP_TRY(hipMemcpyAsync(grad, c->d_grad, sizeof(float) * c->P, hipMemcpyDeviceToHost, c->stream));
+    if (theta) HIP_TRY(hipMemcpyAsync(theta, c->d_theta, sizeof(float) * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (I_stddev) *I_stddev = c->h_meta[slot].I_stddev;
+    return SDM_OK;
+}
+
+// ---- K1..K3 ----------------------------------------------------------------------------------------------------
+static int launch_search_fuse(sdm_ctx* c, int n_ref, int n)
+{
+    StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);
+    const size_t lds = search_lds_bytes(n);
+    const int grid = grid_blocks(c->geom, n_ref);
+    if (c->stats_on)
+        hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
+                           c->d_pairs, n_ref, n, c->geom, c->dprm, c->pool, c->d_stats);
+    else
+        hipLaunchKernelGGL(k_search_fuse<false>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
+                           c->d_pairs, n_ref, n, c->geom, c->dprm, c->pool, c->d_stats);
+    HIP_TRY(hipGetLastError());
+    return SDM_OK;
+}
+
+int sdm_search_fuse(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, const float* rot,
+                    const float* mind, const float* maxd)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
+    if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
+    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
+    if (rc) return rc;
+    if ((rc = launch_search_fuse(c, n_ref, n))) return rc;
+    for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;
+    return tables_staged(c);
+}
+
+// stencil passes over [first, first+count) of the staged reference list.
+// mode 0: check pool -> scratch; mode 1: grow scratch -> pool; mode 2: check pool->scratch then copy back
+static int launch_intra(sdm_ctx* c, int first, int count, bool check, bool grow)
+{
+    // offsets: [0..K) pool offsets, [K..2K) scratch offsets, [2K..3K) record offsets (in floats)
+    const int K = c->cap_refs;
+    const int grid = grid_blocks(c->geom, count);
+    if (check) {
+        hipLaunchKernelGGL(k_intra_check, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
+                           c->d_off + first, c->d_off + K + first, count, c->geom);
+        HIP_TRY(hipGetLastError());
+    }
+    if (grow) {
+        hipLaunchKernelGGL(k_intra_grow, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
+                           c->d_off + K + first, c->d_off + first, (const float*)c->rec, c->d_off + 2 * K + first, 4,
+                           count, c->geom, c->dprm.lambdaG);
+        HIP_TRY(hipGetLastError());
+    }
+    return SDM_OK;
+}
+
+static int stage_offsets(sdm_ctx* c, int n_ref, const int* ref_slots)
+{
+    const int K = c->cap_refs, cap = c->cfg.batch_capacity;
+    for (int r = 0; r < n_ref; r++) {
+        c->h_off[r] = (long long)ref_slots[r] * c->P;
+        c->h_off[K + r] = (long long)(r % cap) * c->P;
+        c->h_off[2 * K + r] = (long long)ref_slots[r] * c->P * 4;
+    }
+    for (int k = 0; k < 3; k++)
+        HIP_TRY(hipMemcpyAsync(c->d_off + k * K, c->h_off + k * K, sizeof(long long) * n_ref, hipMemcpyHostToDevice,
+                               c->stream));
+    return SDM_OK;
+}
+
+static int run_intra(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bool grow)
+{
+    // K2 writes scratch, K3 writes back to the pool.  A lone pass is completed by a device copy.
+    int rc = stage_offsets(c, n_ref, ref_slots);
+    if (rc) return rc;
+    StageTimer tm(c, SDM_STAGE_INTRA);
+    const int cap = c->cfg.batch_capacity;
+    for (int first = 0; first < n_ref; first += cap) {
+        const int count = std::min(cap, n_ref - first);
+        if (check && grow) {
+            if ((rc = launch_intra(c, first, count, true, true))) return rc;
+        } else if (check) {
+            if ((rc = launch_intra(c, first, count, true, false))) return rc;
+            for (int r = 0; r < count; r++)
+                HIP_TRY(hipMemcpyAsync(c->pool + c->h_off[first + r], c->scratch + (long long)r * c->P,
+                                       sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            for (int r = 0; r < count; r++)
+                HIP_TRY(hipMemcpyAsync(c->scratch + (long long)r * c->P, c->pool + c->h_off[first + r],
+                                       sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = launch_intra(c, first, count, false, true))) return rc;
+        }
+    }
+    return SDM_OK;
+}
+
+int sdm_intra_check(sdm_ctx* c, int n_ref, const int* ref_slots)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    int rc = stage_tables(c, n_ref, ref_slots, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = run_intra(c, n_ref, ref_slots, true, false))) return rc;
+    return tables_staged(c);
+}
+
+int sdm_intra_grow(sdm_ctx* c, int n_ref, const int* ref_slots)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    int rc = stage_tables(c, n_ref, ref_slots, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = run_intra(c, n_ref, ref_slots, false, true))) return rc;
+    return tables_staged(c);
+}
+
+int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, const float* rot,
+              const float* mind, const float* maxd)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
+    if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
+    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
+    if (rc) return rc;
+    if ((rc = launch_search_fuse(c, n_ref, n))) return rc;            // PM.cc:197-231
+    if ((rc = run_intra(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
+    for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244
+    return tables_staged(c);
+}
+
+// ---- K4 / K5 ------------------------------------------------------------------------------------------------------
+int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, int commit)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
+    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    {
+        StageTimer tm(c, SDM_STAGE_INTER);
+        hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                           c->d_refs, c->d_pairs, n_ref, n, c->geom, c->dprm.lambdaN, c->chk);
+        HIP_TRY(hipGetLastError());
+        if (commit) {
+            hipLaunchKernelGGL(k_commit, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->chk, c->pool,
+                               c->P, c->d_ref_slots, n_ref);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    for (int r = 0; r < n_ref; r++) c->has_chk[ref_slots[r]] = 1;  // kf->interKF_depth_flag_, PM.cc:306
+    return tables_staged(c);
+}
+
+int sdm_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int source)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (!c->xyz) return fail(SDM_ESTATE, "context created without with_pointset");
+    int rc = stage_tables(c, n_ref, ref_slots, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const float* src = source ? c->chk : (const float*)c->pool;
+    const int sstride = source ? 1 : 2;
+    StageTimer tm(c, SDM_STAGE_POINTSET);
+    hipLaunchKernelGGL(k_pointset, dim3(blocks_for(c->P), n_ref), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
+                       c->d_meta, c->d_ref_slots, n_ref, c->W, c->H, c->xyz);
+    HIP_TRY(hipGetLastError());
+    return tables_staged(c);
+}
+
+// ---- map transfer ----------------------------------------------------------------------------------------------------
+static int upload_f2(sdm_ctx* c, float2* dst, const float* rho, const float* sigma)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (long long i = 0; i < c->P; i++) c->h_f2[i] = make_float2(rho[i], sigma[i]);
+    HIP_TRY(hipMemcpyAsync(dst, c->h_f2, sizeof(float2) * c->P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+static int download_f2(sdm_ctx* c, const float2* src, float* rho, float* sigma)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_f2, src, sizeof(float2) * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (long long i = 0; i < c->P; i++) {
+        if (rho) rho[i] = c->h_f2[i].x;
+        if (sigma) sigma[i] = c->h_f2[i].y;
+    }
+    return SDM_OK;
+}
+
+int sdm_upload_depth(sdm_ctx* c, int slot, const float* rho, const float* sigma)
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!rho || !sigma) return fail(SDM_EINVAL, "null map");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->has_depth[slot] = 1;
+    return upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma);
+}
+
+int sdm_download_depth(sdm_ctx* c, int slot, float* rho, float* sigma)
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return download_f2(c, c->pool + (long long)slot * c->P, rho, sigma);
+}
+
+int sdm_download_checked(sdm_ctx* c, int slot, float* rho)
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!rho) return fail(SDM_EINVAL, "null map");
+    if (!c->has_chk[slot]) return fail(SDM_ESTATE, "slot has not been inter-keyframe checked");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(rho, c->chk + (long long)slot * c->P, sizeof(float) * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+int sdm_download_pointset(sdm_ctx* c, int slot, float* xyz)
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!xyz) return fail(SDM_EINVAL, "null map");
+    if (!c->xyz) return fail(SDM_ESTATE, "context created without with_pointset");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(xyz, c->xyz + (long long)slot * c->P * 3, sizeof(float) * 3 * c->P, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+void* sdm_depth_pool_ptr(sdm_ctx* c) { return c ? (void*)c->pool : nullptr; }
+
+// ---- stand-alone map operations (PM.h:85-86 signatures): scratch slot 0 in, slot 1 out -------------------------------------
+static int intra_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad, bool grow)
+{
+    if (!c || !rho || !sigma) return fail(SDM_EINVAL, "null argument");
+    if (grow && !grad) return fail(SDM_EINVAL, "IntraKeyFrameDepthGrowing needs gradimg");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc = wait_tables(c);
+    if (rc) return rc;
+    if ((rc = upload_f2(c, c->scratch, rho, sigma))) return rc;
+    const int K = c->cap_refs;
+    c->h_off[0] = 0;
+    c->h_off[K] = c->P;
+    c->h_off[2 * K] = 0;
+    for (int k = 0; k < 3; k++)
+        HIP_TRY(hipMemcpyAsync(c->d_off + k * K, c->h_off + k * K, sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    const int grid = grid_blocks(c->geom, 1);
+    if (!grow) {
+        hipLaunchKernelGGL(k_intra_check, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->scratch, c->d_off,
+                           c->d_off + K, 1, c->geom);
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_grad, grad, sizeof(float) * c->P, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_intra_grow, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->scratch, c->d_off,
+                           c->d_off + K, (const float*)c->d_grad, c->d_off + 2 * K, 1, 1, c->geom, c->dprm.lambdaG);
+    }
+    HIP_TRY(hipGetLastError());
+    return download_f2(c, c->scratch + c->P, rho, sigma);
+}
+
+int sdm_intra_check_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad)
+{
+    (void)grad;  // the reference's IntraKeyFrameDepthChecking never reads gradimg (PM.cc:486-547)
+    return intra_maps(c, rho, sigma, grad, false);
+}
+int sdm_intra_grow_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad)
+{
+    return intra_maps(c, rho, sigma, grad, true);
+}
+
+// ---- per-pixel entry points ----------------------------------------------------------------------------------------------
+static int read_small(sdm_ctx* c, float* out, int n)
+{
+    HIP_TRY(hipMemcpyAsync(out, c->d_small, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+int sdm_epipolar_search(sdm_ctx* c, int ref_slot, int nbr_slot, int x, int y, float mind, float maxd, float rot,
+                        float out[5])
+{
+    if (!c || !out) return fail(SDM_EINVAL, "null argument");
+    if (x < 0 || x >= c->W || y < 0 || y >= c->H) return fail(SDM_EINVAL, "pixel out of range");
+    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, &rot, &mind, &maxd);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_epipolar_search_px, dim3(1), dim3(1), 0, c->stream, c->rec, c->P, c->d_refs, c->d_pairs, c->W,
+                       c->H, x, y, c->dprm, c->d_small);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tables_staged(c))) return rc;
+    return read_small(c, out, 5);
+}
+
+int sdm_search_range(sdm_ctx* c, int ref_slot, int nbr_slot, int x, int y, float mind, float maxd, float* umin,
+                     float* umax)
+{
+    if (!c || !umin || !umax) return fail(SDM_EINVAL, "null argument");
+    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, nullptr, &mind, &maxd);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_search_range_px, dim3(1), dim3(1), 0, c->stream, c->d_refs, c->d_pairs, c->W, x, y, c->d_small);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tables_staged(c))) return rc;
+    float o[2];
+    if ((rc = read_small(c, o, 2))) return rc;
+    *umin = o[0];
+    *umax = o[1];
+    return SDM_OK;
+}
+
+int sdm_fuse(sdm_ctx* c, const float* rho, const float* sigma, int n, float out[3])
+{
+    if (!c || !out || (n > 0 && (!rho || !sigma))) return fail(SDM_EINVAL, "null argument");
+    if (n < 0 || n > SDM_MAX_NEIGHBOURS) return fail(SDM_EINVAL, "n out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) c->h_f2[i] = make_float2(rho[i], sigma[i]);
+    HIP_TRY(hipMemcpyAsync(c->scratch, c->h_f2, sizeof(float2) * std::max(n, 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_fuse_px, dim3(1), dim3(1), 0, c->stream, c->scratch, n, c->dprm.lambdaN, c->d_small);
+    HIP_TRY(hipGetLastError());
+    return read_small(c, out, 3);
+}
+
+int sdm_pair_geometry(sdm_ctx* c, int ref_slot, int nbr_slot, float F12[9], float R21[9], float t21[3])
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = tables_staged(c))) return rc;
+    PairConst pc;
+    HIP_TRY(hipMemcpyAsync(&pc, c->d_pairs, sizeof(PairConst), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (F12) memcpy(F12, pc.F, sizeof(float) * 9);
+    if (R21) memcpy(R21, pc.R, sizeof(float) * 9);
+    if (t21) memcpy(t21, pc.t, sizeof(float) * 3);
+    return SDM_OK;
+}
+
+// ---- host helpers of the class surface --------------------------------------------------------------------------------------
+int sdm_stereo_search_constraints(const float* d, int n, float* min_depth, float* max_depth)
+{
+    if (!d || n <= 0 || !min_depth || !max_depth) return fail(SDM_EINVAL, "bad argument");
+    // PM.cc:373: std::accumulate(..., 0.0) accumulates in double
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) acc = acc + (double)d[i];
+    float sum = (float)acc;
+    float mean = sum / (float)n;
+    double acc2 = 0.0;  // PM.cc:378: std::inner_product(..., 0.0) over float differences
+    for (int i = 0; i < n; i++) {
+        float diff = d[i] - mean;
+        float pr = diff * diff;
+        acc2 = acc2 + (double)pr;
+    }
+    float variance = (float)(acc2 / (double)n);
+    float stdev = std::sqrt(variance);
+    *max_depth = 1.0f / (mean + 2.0f * stdev);  // PM.cc:381
+    *min_depth = 1.0f / (mean - 2.0f * stdev);  // PM.cc:382
+    return SDM_OK;
+}
+
+float sdm_median_rot_in_plane(const int* mp1, const float* angle1, int n1, const int* mp2, const float* angle2, int n2)
+{
+    std::vector<float> rot;  // PM.cc:467-484
+    for (int i = 0; i < n1; i++) {
+        if (mp1[i] < 0) continue;
+        for (int j = 0; j < n2; j++) {
+            if (mp2[j] != mp1[i]) continue;
+            if (angle1[i] < 0 || angle2[j] < 0) continue;
+            rot.push_back(angle2[j] - angle1[i]);
+        }
+    }
+    if (rot.empty()) return 0.f;  // PM.cc:174-177
+    std::sort(rot.begin(), rot.end());
+    return rot[(rot.size() - 1) / 2];
+}
+
+// ---- instrumentation ------------------------------------------------------------------------------------------------------------
+int sdm_enable_stats(sdm_ctx* c, int on)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    c->stats_on = on != 0;
+    return SDM_OK;
+}
+
+int sdm_enable_timing(sdm_ctx* c, int on)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    c->timing_on = on != 0;
+    return SDM_OK;
+}
+
+int sdm_get_timing(sdm_ctx* c, double ms_total[SDM_NUM_STAGES], long long launches[SDM_NUM_STAGES], int reset)
+{
+    if (!c || !ms_total || !launches) return fail(SDM_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < SDM_NUM_STAGES; i++) {
+        ms_total[i] = 0.0;
+        launches[i] = 0;
+    }
+    for (size_t i = 0; i < c->spans_used; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->spans[i].a, c->spans[i].b));
+        ms_total[c->spans[i].stage] += (double)ms;
+        launches[c->spans[i].stage]++;
+    }
+    if (reset) c->spans_used = 0;
+    return SDM_OK;
+}
+
+int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
+{
+    if (!c || !out) return fail(SDM_EINVAL, "null argument");
+    unsigned long long v[8];
+    HIP_TRY(hipMemcpyAsync(v, c->d_stats, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->searches = (long long)v[0];
+    out->candidates = (long long)v[1];
+    out->gate_pass = (long long)v[2];
+    out->hypotheses = (long long)v[3];
+    out->fused = (long long)v[4];
+    if (reset) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(v), c->stream));
+    return SDM_OK;
+}
+
+}  // extern "C"

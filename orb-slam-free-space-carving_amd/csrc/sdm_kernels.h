@@ -1,0 +1,625 @@
+// sdm_kernels.h -- gfx950 kernels of the ProbabilityMapping path (included by sdm_engine.hip).
+//
+// Common shape of K1..K4: one 256-thread workgroup per 64x16 pixel tile of one reference keyframe.
+// The workgroup compacts the tile's ACTIVE pixels (the ~20 % that pass the reference's per-pixel
+// gate) into LDS in raster order, so waves are not spent on skipped pixels; thread t then owns
+// active pixel t and loops the neighbour index j uniformly, which keeps the per-(ref,nbr)
+// constants in scalar registers and the scan lengths of adjacent lanes similar.  Results are
+// staged in an LDS copy of the tile and written back with coalesced 8-byte stores.
+//
+// Block -> (reference, tile) mapping is XCD-aware: blocks b and b+8 share an XCD (round-robin
+// dispatch), so tile t of EVERY reference keyframe is given to XCD t%8; consecutive reference
+// keyframes read the same neighbour-image region from that XCD's L2 instead of re-fetching it.
+#pragma once
+#include "sdm_device.h"
+
+namespace sdm {
+
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 16;
+constexpr int TILE_PX = TILE_W * TILE_H;  // 1024
+constexpr int BLOCK = 256;
+constexpr int PX_PER_THREAD = TILE_PX / BLOCK;  // 4
+
+struct TileGeom {
+    int W, H, tiles_x, tiles_y, ntiles;
+};
+
+__host__ __device__ inline TileGeom make_geom(int W, int H)
+{
+    TileGeom g;
+    g.W = W;
+    g.H = H;
+    g.tiles_x = (W + TILE_W - 1) / TILE_W;
+    g.tiles_y = (H + TILE_H - 1) / TILE_H;
+    g.ntiles = g.tiles_x * g.tiles_y;
+    return g;
+}
+__host__ inline int grid_blocks(const TileGeom& g, int n_ref) { return 8 * ((g.ntiles + 7) / 8) * n_ref; }
+
+// XCD-aware decode; returns false for padding blocks.
+__device__ __forceinline__ bool decode_block(const TileGeom& g, int n_ref, int& ref, int& tx0, int& ty0)
+{
+    int b = blockIdx.x;
+    int xcd = b & 7, i = b >> 3;
+    int tpx = (g.ntiles + 7) >> 3;
+    ref = i / tpx;
+    int tile = (i - ref * tpx) * 8 + xcd;
+    if (ref >= n_ref || tile >= g.ntiles) return false;
+    int ty = tile / g.tiles_x;
+    tx0 = (tile - ty * g.tiles_x) * TILE_W;
+    ty0 = ty * TILE_H;
+    return true;
+}
+
+// Ordered compaction of up to 4 flags per thread (local index L = i*256 + tid) into act[].
+// wsum: 16 ints of LDS.  Returns the number of active pixels.  Contains one __syncthreads().
+__device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], unsigned short* act, int* wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pre[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        unsigned long long m = __ballot(f[i]);
+        pre[i] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[i * 4 + wave] = __popcll(m);
+    }
+    __syncthreads();
+    int run = 0, total = 0;
+    int off[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w == wave) off[i] = run;
+            run += wsum[i * 4 + w];
+        }
+    }
+    total = run;
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++)
+        if (f[i]) act[off[i] + pre[i]] = (unsigned short)(i * BLOCK + tid);
+    return total;
+}
+
+// ---- K0: input pre-pass ---------------------------------------------------------------------------
+// Scharr/32 gradient, magnitude, fastAtan2 phase (the pre-processing PM.cc assumes on KeyFrame:
+// GradImg / GradTheta) + exact integer sums for I_stddev.
+__global__ __launch_bounds__(BLOCK) void k_gradient(const uint8_t* __restrict__ im, int W, int H,
+                                                    float* __restrict__ grad, float* __restrict__ theta,
+                                                    unsigned long long* __restrict__ sums)
+{
+    int idx = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long s = 0, sq = 0;
+    if (idx < W * H) {
+        int y = idx / W, x = idx - y * W;
+        int ym = max(y - 1, 0), yp = min(y + 1, H - 1), xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+        int a00 = im[ym * W + xm], a01 = im[ym * W + x], a02 = im[ym * W + xp];
+        int a10 = im[y * W + xm], a11 = im[y * W + x], a12 = im[y * W + xp];
+        int a20 = im[yp * W + xm], a21 = im[yp * W + x], a22 = im[yp * W + xp];
+        int sx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
+        int sy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
+        float gx = (float)sx * (1.0f / 32.0f), gy = (float)sy * (1.0f / 32.0f);
+        float xx = gx * gx, yy = gy * gy;
+        grad[idx] = sqrtf(xx + yy);
+        theta[idx] = fast_atan2_deg(gy, gx);
+        s = (unsigned long long)a11;
+        sq = (unsigned long long)(a11 * a11);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        sq += __shfl_down(sq, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], s);
+        atomicAdd(&sums[1], sq);
+    }
+}
+
+__global__ void k_istd_finish(const unsigned long long* __restrict__ sums, int W, int H, KfMeta* meta)
+{
+    double n = (double)W * (double)H;
+    double mean = (double)sums[0] / n;
+    double var = (double)sums[1] / n - mean * mean;
+    if (var < 0) var = 0;
+    meta->I_stddev = (float)sqrt(var);
+}
+
+// pack im/grad/theta planes into the 16-byte search records (layout: sdm_device.h)
+__global__ __launch_bounds__(BLOCK) void k_pack(const uint8_t* __restrict__ im, const float* __restrict__ grad,
+                                                const float* __restrict__ theta, int W, int H,
+                                                float4* __restrict__ rec)
+{
+    int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= W * H) return;
+    int y = idx / W;
+    bool below = (y + 1 < H);
+    unsigned bits = (unsigned)im[idx] | ((below ? (unsigned)im[idx + W] : 0u) << 8);
+    float4 r;
+    r.x = grad[idx];
+    r.y = theta[idx];
+    r.z = below ? grad[idx + W] : 0.0f;
+    r.w = __uint_as_float(bits);
+    rec[idx] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_unpack(const float4* __restrict__ rec, int n, uint8_t* __restrict__ im,
+                                                  float* __restrict__ grad, float* __restrict__ theta)
+{
+    int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    float4 r = rec[idx];
+    im[idx] = (uint8_t)(__float_as_uint(r.w) & 0xffu);
+    grad[idx] = r.x;
+    theta[idx] = r.y;
+}
+
+// ---- per-batch constant tables ----------------------------------------------------------------------
+// One thread per (reference, neighbour): the host work of PM.cc:170-195 (F12, R21, t21) done on
+// device from the resident keyframe metadata, so a batch needs only slot indices from the host.
+__global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restrict__ ref_slots,
+                             const int* __restrict__ nbr_slots, const float* __restrict__ rot,
+                             const float* __restrict__ mind, const float* __restrict__ maxd, int n_ref, int n,
+                             RefConst* __restrict__ refs, PairConst* __restrict__ pairs)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_ref * n) return;
+    int r = idx / n, j = idx - r * n;
+    KfMeta m1 = meta[ref_slots[r]];
+    KfMeta m2 = meta[nbr_slots[idx]];
+    PairConst pc;
+    pair_geometry(m1, m2, pc.F, pc.R, pc.t);
+    pc.rot = rot ? rot[idx] : 0.0f;
+    pc.istd = m2.I_stddev;
+    pc.nbr_slot = nbr_slots[idx];
+    pc.nfx = m2.fx;
+    pc.nfy = m2.fy;
+    pc.ncx = m2.cx;
+    pc.ncy = m2.cy;
+    pc.pad[0] = pc.pad[1] = pc.pad[2] = pc.pad[3] = 0.f;
+    pairs[idx] = pc;
+    if (j == 0) {
+        RefConst rc;
+        rc.slot = ref_slots[r];
+        rc.fx = m1.fx;
+        rc.fy = m1.fy;
+        rc.cx = m1.cx;
+        rc.cy = m1.cy;
+        rc.mind = mind ? mind[r] : 0.f;
+        rc.maxd = maxd ? maxd[r] : 0.f;
+        rc.pad = 0;
+        refs[r] = rc;
+    }
+}
+
+// ---- K1: epipolar search + hypothesis fusion, PM.cc:197-231 --------------------------------------------
+// Dynamic LDS: float2 hyp[n][256] -- thread-private hypothesis columns (depth_ho of PM.cc:204).
+template <bool STATS>
+__global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict__ rec, long long plane,
+                                                       const RefConst* __restrict__ refs,
+                                                       const PairConst* __restrict__ pairs, int n_ref, int n,
+                                                       TileGeom g, DevParams prm, float2* __restrict__ pool,
+                                                       unsigned long long* __restrict__ stats)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float2* hyp = reinterpret_cast<float2*>(smem_raw);
+    __shared__ float2 outv[TILE_PX];
+    __shared__ unsigned short act[TILE_PX];
+    __shared__ int wsum[16];
+
+    int ref, tx0, ty0;
+    if (!decode_block(g, n_ref, ref, tx0, ty0)) return;
+    const int tid = threadIdx.x;
+    const int W = g.W, H = g.H;
+    const RefConst rc = refs[ref];
+    const float4* __restrict__ rrec = rec + (long long)rc.slot * plane;
+
+    bool f[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);  // PM.cc:198-199
+        float gr = inset ? rrec[y * W + x].x : 0.0f;
+        f[i] = inset && !(gr < prm.lambdaG);  // PM.cc:201
+        outv[L] = make_float2(0.f, 0.f);
+    }
+    const int nAct = block_compact(f, act, wsum);
+    __syncthreads();
+
+    SearchStats st = {0, 0, 0};
+    unsigned long long n_hyp = 0, n_fused = 0;
+    const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
+    for (int base = 0; base < nAct; base += BLOCK) {
+        const int t = base + tid;
+        const bool on = t < nAct;
+        const int L = on ? act[t] : 0;
+        const int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        float pixel = 0.f, grad1 = 0.f, th_pi = 0.f, xp0 = 0.f, xp1 = 0.f;
+        if (on) {
+            float4 r = rrec[y * W + x];
+            pixel = (float)(int)(__float_as_uint(r.w) & 0xffu);  // PM.cc:202
+            grad1 = r.x;
+            th_pi = r.y;                    // PM.cc:214
+            xp0 = ((float)x - rc.cx) / rc.fx;  // PM.cc:862
+            xp1 = ((float)y - rc.cy) / rc.fy;
+        }
+        int nh = 0;
+        for (int j = 0; j < n; j++) {
+            const PairConst* __restrict__ pc = pcs + j;
+            const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
+            if (on) {
+                float rho, sigma, bu, bv;
+                bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0,
+                                                 xp1, rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
+                if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
+                    hyp[nh * BLOCK + tid] = make_float2(rho, sigma);
+                    nh++;
+                }
+            }
+        }
+        if (STATS) n_hyp += (unsigned long long)nh;
+        if (on && nh > prm.lambdaN) {  // PM.cc:221
+            float rho, sigma;
+            if (fuse_column(hyp + tid, BLOCK, nh, prm.lambdaN, rho, sigma)) {  // PM.cc:223-227
+                outv[L] = make_float2(rho, sigma);
+                if (STATS) n_fused++;
+            }
+        }
+    }
+    __syncthreads();
+    float2* __restrict__ out = pool + (long long)rc.slot * plane;
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        if (x < W && y < H) out[y * W + x] = outv[L];
+    }
+    if (STATS) {
+        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass, n_hyp, n_fused};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            unsigned long long s = v[k];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if ((tid & 63) == 0 && s) atomicAdd(&stats[k], s);
+        }
+    }
+}
+
+// ---- shared halo loader for the 3x3 stencil kernels -----------------------------------------------------
+constexpr int HALO_W = TILE_W + 2;
+constexpr int HALO_H = TILE_H + 2;
+__device__ __forceinline__ void load_halo(const float2* __restrict__ in, int W, int H, int tx0, int ty0,
+                                          float2* tile)
+{
+    for (int i = threadIdx.x; i < HALO_W * HALO_H; i += BLOCK) {
+        int hy = i / HALO_W, hx = i - hy * HALO_W;
+        int x = tx0 + hx - 1, y = ty0 + hy - 1;
+        float2 v = make_float2(0.f, 0.f);
+        if (x >= 0 && x < W && y >= 0 && y < H) v = in[y * W + x];
+        tile[i] = v;
+    }
+}
+
+// ---- K2: IntraKeyFrameDepthChecking, PM.cc:486-547 -------------------------------------------------------
+// jobs[i] = {in offset, out offset} (float2 elements) of reference i.
+__global__ __launch_bounds__(BLOCK) void k_intra_check(const float2* __restrict__ in_base, float2* __restrict__ out_base,
+                                                       const long long* __restrict__ in_off,
+                                                       const long long* __restrict__ out_off, int n_ref, TileGeom g)
+{
+    __shared__ float2 tile[HALO_W * HALO_H];
+    __shared__ float2 outv[TILE_PX];
+    __shared__ unsigned short act[TILE_PX];
+    __shared__ int wsum[16];
+    int ref, tx0, ty0;
+    if (!decode_block(g, n_ref, ref, tx0, ty0)) return;
+    const int tid = threadIdx.x, W = g.W, H = g.H;
+    const float2* __restrict__ in = in_base + in_off[ref];
+    float2* __restrict__ out = out_base + out_off[ref];
+    load_halo(in, W, H, tx0, ty0, tile);
+    __syncthreads();
+    bool f[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int lx = L & (TILE_W - 1), ly = L >> 6;
+        int x = tx0 + lx, y = ty0 + ly;
+        float2 c = tile[(ly + 1) * HALO_W + lx + 1];
+        outv[L] = c;  // depth_map_new = depth_map.clone(), PM.cc:488-489
+        bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);
+        f[i] = inset && ((double)c.x > 0.000001);  // PM.cc:497
+    }
+    const int nAct = block_compact(f, act, wsum);
+    __syncthreads();
+    for (int base = 0; base < nAct; base += BLOCK) {
+        const int t = base + tid;
+        if (t >= nAct) continue;
+        const int L = act[t];
+        const int lx = L & (TILE_W - 1), ly = L >> 6;
+        const float2 c = tile[(ly + 1) * HALO_W + lx + 1];
+        // compatible_neighbor_ho in raster order, then itself (PM.cc:504-522); GetFusion B streamed
+        float pjsj = 0.f, rsj = 0.f, tmin = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (k == 4) continue;
+            float2 v = tile[(ly + k / 3) * HALO_W + lx + (k % 3)];
+            if ((double)v.x > 0.000001 && chi_test(v.x, c.x, v.y, c.y)) {  // PM.cc:510-512
+                if (cnt == 0) tmin = v.y;
+                fusion_accum(v.x, v.y, pjsj, rsj);
+                if ((double)v.y * (double)v.y < (double)tmin * (double)tmin) tmin = v.y;  // PM.cc:958
+                cnt++;
+            }
+        }
+        if (cnt == 0) tmin = c.y;
+        fusion_accum(c.x, c.y, pjsj, rsj);
+        if ((double)c.y * (double)c.y < (double)tmin * (double)tmin) tmin = c.y;
+        cnt++;
+        if (cnt >= 3)
+            outv[L] = make_float2(pjsj / rsj, tmin);  // PM.cc:530-531 (sigma := min sigma)
+        else
+            outv[L] = make_float2(0.f, 0.f);  // PM.cc:535-536
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        if (x < W && y < H) out[y * W + x] = outv[L];
+    }
+}
+
+// ---- K3: IntraKeyFrameDepthGrowing, PM.cc:549-596 --------------------------------------------------------
+// grad is read with element stride gstride from grad_base + grad_off[ref] (4 for the record plane).
+__global__ __launch_bounds__(BLOCK) void k_intra_grow(const float2* __restrict__ in_base, float2* __restrict__ out_base,
+                                                      const long long* __restrict__ in_off,
+                                                      const long long* __restrict__ out_off,
+                                                      const float* __restrict__ grad_base,
+                                                      const long long* __restrict__ grad_off, int gstride, int n_ref,
+                                                      TileGeom g, float lambdaG)
+{
+    __shared__ float2 tile[HALO_W * HALO_H];
+    __shared__ float2 outv[TILE_PX];
+    __shared__ unsigned short act[TILE_PX];
+    __shared__ int wsum[16];
+    int ref, tx0, ty0;
+    if (!decode_block(g, n_ref, ref, tx0, ty0)) return;
+    const int tid = threadIdx.x, W = g.W, H = g.H;
+    const float2* __restrict__ in = in_base + in_off[ref];
+    float2* __restrict__ out = out_base + out_off[ref];
+    const float* __restrict__ grad = grad_base + grad_off[ref];
+    load_halo(in, W, H, tx0, ty0, tile);
+    __syncthreads();
+    bool f[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int lx = L & (TILE_W - 1), ly = L >> 6;
+        int x = tx0 + lx, y = ty0 + ly;
+        float2 c = tile[(ly + 1) * HALO_W + lx + 1];
+        outv[L] = c;
+        bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);
+        bool cand = inset && ((double)c.x < 0.000001);  // PM.cc:560
+        if (cand) cand = !(grad[(long long)(y * W + x) * gstride] < lambdaG);  // PM.cc:562
+        f[i] = cand;
+    }
+    const int nAct = block_compact(f, act, wsum);
+    __syncthreads();
+    for (int base = 0; base < nAct; base += BLOCK) {
+        const int t = base + tid;
+        if (t >= nAct) continue;
+        const int L = act[t];
+        const int lx = L & (TILE_W - 1), ly = L >> 6;
+        const float2 c = tile[(ly + 1) * HALO_W + lx + 1];
+        float pjsj = 0.f, rsj = 0.f, smin = 0.f;  // GetFusion overload A, PM.cc:926-945
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (k == 4) continue;
+            float2 v = tile[(ly + k / 3) * HALO_W + lx + (k % 3)];
+            if (chi_test(v.x, c.x, v.y, c.y)) {  // PM.cc:571
+                if (cnt == 0) smin = v.y;
+                fusion_accum(v.x, v.y, pjsj, rsj);
+                if (v.y < smin) smin = v.y;  // PM.cc:939
+                cnt++;
+            }
+        }
+        if (cnt >= 2) outv[L] = make_float2(pjsj / rsj, smin);  // PM.cc:581-587
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        if (x < W && y < H) out[y * W + x] = outv[L];
+    }
+}
+
+// ---- K4: InterKeyFrameDepthChecking, PM.cc:628-799 ------------------------------------------------------
+// Reads the neighbours' {rho,sigma} from the depth pool (4 taps, PM.cc:705-752), writes the
+// reference keyframe's checked rho to chk[slot].
+__global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict__ pool, long long plane,
+                                                       const RefConst* __restrict__ refs,
+                                                       const PairConst* __restrict__ pairs, int n_ref, int n,
+                                                       TileGeom g, int lambdaN, float* __restrict__ chk)
+{
+    __shared__ float outv[TILE_PX];
+    __shared__ unsigned short act[TILE_PX];
+    __shared__ int wsum[16];
+    int ref, tx0, ty0;
+    if (!decode_block(g, n_ref, ref, tx0, ty0)) return;
+    const int tid = threadIdx.x, W = g.W, H = g.H;
+    const RefConst rc = refs[ref];
+    const float2* __restrict__ cur = pool + (long long)rc.slot * plane;
+    bool f[PX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        float r = (x < W && y < H) ? cur[y * W + x].x : 0.f;
+        outv[L] = r;
+        bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);  // PM.cc:659-660
+        f[i] = inset && !((double)r < 0.000001);                      // PM.cc:662
+    }
+    const int nAct = block_compact(f, act, wsum);
+    __syncthreads();
+    const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
+    const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
+    for (int base = 0; base < nAct; base += BLOCK) {
+        const int t = base + tid;
+        const bool on = t < nAct;
+        const int L = on ? act[t] : 0;
+        const int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        const float depthp = outv[L];
+        const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
+        const float dp = 1 / depthp;                                                        // PM.cc:769
+        int kf_count = 0;
+        float sum_Jr = 0.f, sum_JJ = 0.f;
+        for (int j = 0; j < n; j++) {
+            const PairConst* __restrict__ pc = pcs + j;
+            if (!on) continue;
+            const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
+            float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
+            float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
+            float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+            float t2 = rzxp / depthp + pc->t[2];
+            float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
+            float v = pc->nfy * t1 + pc->ncy * t2;
+            float xj = u / t2, yj = v / t2;  // PM.cc:680
+            float denom2 = depthp * pc->t[2];
+            float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+            if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) continue;  // PM.cc:695
+            int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
+            int nj = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+                int tx = x0 + (k >> 1), ty = y0 + (k & 1);
+                float2 h = nb[ty * W + tx];
+                if ((double)h.x > 0.000001) {
+                    float dd = depthj - h.x;
+                    float test = (float)(((double)dd * (double)dd) / ((double)h.y * (double)h.y));  // PM.cc:709
+                    if ((double)test < 3.84) {
+                        nj++;
+                        float djn = 1 / h.x;  // PM.cc:777-783
+                        float d2sigma = djn * djn * h.y;
+                        float J = -rzxp / d2sigma;
+                        float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;
+                        sum_Jr = sum_Jr + J * r0;
+                        sum_JJ = sum_JJ + J * J;
+                    }
+                }
+            }
+            if (nj >= 1) kf_count++;  // PM.cc:755
+        }
+        if (on) {
+            if (kf_count < lambdaN) {
+                outv[L] = 0.0f;  // PM.cc:764
+            } else {
+                float dpDelta = (-sum_Jr) / sum_JJ;  // PM.cc:788-791
+                outv[L] = 1 / (dp + dpDelta);       // PM.cc:793
+            }
+        }
+    }
+    __syncthreads();
+    float* __restrict__ out = chk + (long long)rc.slot * plane;
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + tid;
+        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
+        if (x < W && y < H) out[y * W + x] = outv[L];
+    }
+}
+
+// chk -> depth map rho (the reference's in-place write, PM.cc:764/793)
+__global__ __launch_bounds__(BLOCK) void k_commit(const float* __restrict__ chk, float2* __restrict__ pool,
+                                                  long long plane, const int* __restrict__ slots, int n_ref)
+{
+    long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= plane * n_ref) return;
+    int r = (int)(idx / plane);
+    long long p = idx - (long long)r * plane;
+    long long o = (long long)slots[r] * plane + p;
+    pool[o].x = chk[o];
+}
+
+// depth map rho -> chk (so that sdm_pointset(source=1) is defined for never-checked slots is NOT
+// needed; kept minimal on purpose)
+
+// ---- K5: UpdateSemiDensePointSet, PM.cc:337-367 ------------------------------------------------------------
+// src: rho read with element stride sstride from src_base + slot*plane*sstride.
+__global__ __launch_bounds__(BLOCK) void k_pointset(const float* __restrict__ src_base, int sstride, long long plane,
+                                                    const KfMeta* __restrict__ meta, const int* __restrict__ slots,
+                                                    int n_ref, int W, int H, float* __restrict__ xyz)
+{
+    int r = blockIdx.y;
+    int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_ref || idx >= W * H) return;
+    int y = idx / W, x = idx - y * W;
+    if (!(x >= 2 && x < W - 2 && y >= 2 && y < H - 2)) return;  // PM.cc:340-342
+    const int slot = slots[r];
+    const KfMeta m = meta[slot];
+    // Twc = [Rcw^T | -Rcw^T tcw], src/KeyFrame.cc:70-84
+    float Rwc[9], Ow[3], tcw[3] = {m.Tcw[3], m.Tcw[7], m.Tcw[11]};
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) Rwc[i * 3 + k] = m.Tcw[k * 4 + i];
+    mat3_vec(Rwc, tcw, Ow);
+    float inv_d = src_base[((long long)slot * plane + idx) * sstride];
+    float* o = xyz + ((long long)slot * plane + idx) * 3;
+    if ((double)inv_d < 0.000001) {  // PM.cc:345
+        o[0] = 0.f;
+        o[1] = 0.f;
+        o[2] = 0.f;
+        return;
+    }
+    float Z = 1 / inv_d;
+    float X = Z * ((float)x - m.cx) / m.fx;
+    float Y = Z * ((float)y - m.cy) / m.fy;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = ((Rwc[i * 3 + 0] * X + Rwc[i * 3 + 1] * Y) + Rwc[i * 3 + 2] * Z) + (-Ow[i]) * 1.0f;
+}
+
+// ---- single-thread kernels behind the per-pixel C entry points ------------------------------------------------
+__global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long plane, const RefConst* refs,
+                                     const PairConst* pairs, int W, int H, int x, int y, DevParams prm,
+                                     float* __restrict__ out)
+{
+    const RefConst rc = refs[0];
+    const PairConst* pc = pairs;
+    const float4* rrec = rec + (long long)rc.slot * plane;
+    const float4* nrec = rec + (long long)pc->nbr_slot * plane;
+    float4 r = rrec[y * W + x];
+    float pixel = (float)(int)(__float_as_uint(r.w) & 0xffu);
+    float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;
+    float rho, sigma, bu, bv;
+    SearchStats st = {0, 0, 0};
+    bool ok = epipolar_search<false>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, r.x, r.y, xp0, xp1, rc.mind,
+                                     rc.maxd, prm, rho, sigma, bu, bv, &st);
+    out[0] = rho;
+    out[1] = sigma;
+    out[2] = ok ? 1.f : 0.f;
+    out[3] = bu;
+    out[4] = bv;
+}
+
+__global__ void k_search_range_px(const RefConst* refs, const PairConst* pairs, int W, int x, int y,
+                                  float* __restrict__ out)
+{
+    const RefConst rc = refs[0];
+    float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;
+    float rxxp = row_dot_xp(pairs->R + 0, xp0, xp1), rzxp = row_dot_xp(pairs->R + 6, xp0, xp1);
+    float umin, umax;
+    search_range(rc.fx, rc.cx, rxxp, rzxp, pairs->t[0], pairs->t[2], rc.mind, rc.maxd, W, umin, umax);
+    out[0] = umin;
+    out[1] = umax;
+}
+
+__global__ void k_fuse_px(const float2* __restrict__ hyp, int n, int lambdaN, float* __restrict__ out)
+{
+    float rho = 0.f, sigma = 0.f;
+    bool ok = fuse_column(hyp, 1, n, lambdaN, rho, sigma);
+    out[0] = ok ? rho : 0.f;
+    out[1] = ok ? sigma : 0.f;
+    out[2] = ok ? 1.f : 0.f;
+}
+
+}  // namespace sdm

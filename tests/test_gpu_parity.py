@@ -1,0 +1,397 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI, include/sdm_c.h) against the CPU
+oracle on the same seeded inputs.  Bar: BIT-EXACT for every output -- support masks, rho, sigma,
+checked rho and the point set -- because both sides evaluate the same IEEE operation sequence with
+FMA contraction off (the stated float tolerance of BASELINE.json is therefore 0 ulp here; the
+full-size tests in test_gpu_fullsize.py state their own tolerances)."""
+import numpy as np
+import pytest
+
+from common import Sequence, assert_bit_equal, oracle_inter, oracle_pipeline
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def seq_small(pkg, oracle):
+    return Sequence(pkg, oracle, 64, 48, 8, 0x5EED0A01)
+
+
+@pytest.fixture(scope="module")
+def seq_mid(pkg, oracle):
+    return Sequence(pkg, oracle, 160, 120, 8, 0x5EED0A02)
+
+
+@pytest.fixture(scope="module")
+def seq_ragged(pkg, oracle):
+    # W, H not multiples of the 64x16 tile; N = 20 neighbours
+    return Sequence(pkg, oracle, 200, 75, 21, 0x5EED0A03, disparity_px=1.5)
+
+
+def make_engine(pkg, seq, n, **kw):
+    eng = pkg.Engine(seq.W, seq.H, seq.n_kf, max_neighbours=n, **kw)
+    seq.upload(eng)
+    return eng
+
+
+def test_device_is_gfx950(pkg, gpu_ok):
+    eng = pkg.Engine(64, 48, 2)
+    assert eng.arch().startswith("gfx950"), eng.arch()
+    eng.close()
+
+
+def test_prepass_parity(pkg, oracle, gpu_ok, seq_mid):
+    """device Scharr/magnitude/phase/sigma_I == oracle pre-pass, bit for bit"""
+    eng = pkg.Engine(seq_mid.W, seq_mid.H, 2)
+    for k in range(2):
+        eng.upload_image(k, seq_mid.im[k], seq_mid.K, seq_mid.Tcw[k])
+        im, g, t, s = eng.download_inputs(k)
+        assert (im == seq_mid.im[k]).all()
+        assert_bit_equal(g, seq_mid.grad[k], "GradImg")
+        assert_bit_equal(t, seq_mid.theta[k], "GradTheta")
+        assert np.float32(s) == np.float32(seq_mid.istd[k])
+    eng.close()
+
+
+def test_upload_roundtrip(pkg, oracle, gpu_ok, seq_small):
+    eng = make_engine(pkg, seq_small, 7)
+    im, g, t, s = eng.download_inputs(3)
+    assert (im == seq_small.im[3]).all()
+    assert_bit_equal(g, seq_small.grad[3])
+    assert_bit_equal(t, seq_small.theta[3])
+    eng.close()
+
+
+def test_pair_geometry_and_range(pkg, oracle, gpu_ok, seq_mid):
+    eng = make_engine(pkg, seq_mid, 7)
+    rng = np.random.default_rng(1)
+    for (a, b) in [(3, 4), (3, 0), (0, 7), (5, 2)]:
+        F, R, t = eng.pair_geometry(a, b)
+        p = oracle.pair_geometry(seq_mid.okf[a], seq_mid.okf[b])
+        assert_bit_equal(F, np.array(p.F12[:]), "F12")
+        assert_bit_equal(R, np.array(p.R21[:]), "R21")
+        assert_bit_equal(t, np.array(p.t21[:]), "t21")
+        for _ in range(20):
+            x, y = int(rng.integers(0, seq_mid.W)), int(rng.integers(0, seq_mid.H))
+            got = eng.search_range(a, b, x, y, seq_mid.min_depth, seq_mid.max_depth)
+            ref = oracle.search_range(seq_mid.okf[a], p, x, y, seq_mid.min_depth, seq_mid.max_depth)
+            assert_bit_equal(np.array(got), np.array(ref), "GetSearchRange")
+    eng.close()
+
+
+def test_epipolar_search_pixels(pkg, oracle, gpu_ok, seq_mid):
+    """per-pixel EpipolarSearch incl. rot != 0 and degenerate depth bounds"""
+    eng = make_engine(pkg, seq_mid, 7)
+    ys, xs = np.nonzero(seq_mid.grad[3][2:-2, 2:-2] >= 8)
+    rng = np.random.default_rng(2)
+    pick = rng.choice(len(xs), 60, replace=False)
+    n_sup = 0
+    for i in pick:
+        x, y = int(xs[i]) + 2, int(ys[i]) + 2
+        for nbr, rot in [(4, 0.0), (0, 0.0), (7, 3.0), (2, 350.0)]:
+            got = eng.epipolar_search(3, nbr, x, y, seq_mid.min_depth, seq_mid.max_depth, rot)
+            ref = oracle.epipolar_search(seq_mid.okf[3], seq_mid.okf[nbr], x, y, seq_mid.min_depth,
+                                         seq_mid.max_depth, rot)
+            assert got["supported"] == ref["supported"]
+            for key in ("rho", "sigma", "best_u", "best_v"):
+                assert_bit_equal(np.array([got[key]]), np.array([ref[key]]), "%s at %d,%d nbr %d" % (key, x, y, nbr))
+            n_sup += got["supported"]
+    assert n_sup > 30
+    # degenerate bounds: zero-width, swapped, negative, huge
+    for (mn, mx) in [(1.0, 1.0), (0.5, 2.0), (-1.0, 1.0), (1e30, 1e-30), (0.0, 0.0)]:
+        got = eng.epipolar_search(3, 4, int(xs[pick[0]]) + 2, int(ys[pick[0]]) + 2, mn, mx)
+        ref = oracle.epipolar_search(seq_mid.okf[3], seq_mid.okf[4], int(xs[pick[0]]) + 2, int(ys[pick[0]]) + 2, mn, mx)
+        assert got["supported"] == ref["supported"]
+        assert_bit_equal(np.array([got["rho"], got["sigma"]]), np.array([ref["rho"], ref["sigma"]]))
+    eng.close()
+
+
+def test_fuse_hypotheses(pkg, oracle, gpu_ok):
+    eng = pkg.Engine(64, 48, 2, max_neighbours=32)
+    rng = np.random.default_rng(3)
+    cases = []
+    for n in [0, 1, 3, 4, 5, 7, 12, 20, 32]:
+        for _ in range(6):
+            rho = (1.0 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+            sig = (0.02 + 0.05 * rng.random(n)).astype(np.float32)
+            cases.append((rho, sig))
+    # edge cases: zero sigma (0/0 NaN self test), NaN, Inf, exact ties, two equal-size clusters
+    cases.append((np.float32([1, 1, 1, 1]), np.float32([0, 0, 0, 0])))
+    cases.append((np.float32([1, 1, 1, 1, 1]), np.float32([0.1, 0, 0.1, 0.1, np.inf])))
+    cases.append((np.float32([1, np.nan, 1, 1, 1]), np.float32([0.1, 0.1, 0.1, np.nan, 0.1])))
+    cases.append((np.float32([1, 1, 1, 2, 2, 2]), np.float32([0.01] * 6)))
+    cases.append((np.float32([2, 2, 2, 1, 1, 1]), np.float32([0.01] * 6)))
+    cases.append((np.float32([1.0, 1.1, 1.2, 1.3, 1.4]), np.float32([0.05] * 5)))
+    for rho, sig in cases:
+        got = eng.fuse(rho, sig)
+        ref = oracle.fuse(rho, sig)
+        assert got[2] == ref[2], (rho, sig)
+        assert_bit_equal(np.array(got[:2]), np.array(ref[:2]), "fusion %r %r" % (rho, sig))
+    eng.close()
+
+
+@pytest.mark.parametrize("which,n", [("small", 7), ("mid", 7), ("ragged", 20)])
+def test_search_fuse_parity(pkg, oracle, gpu_ok, seq_small, seq_mid, seq_ragged, which, n):
+    """K1 == PM.cc:197-231 on every keyframe of a sequence, batched in one call"""
+    seq = dict(small=seq_small, mid=seq_mid, ragged=seq_ragged)[which]
+    eng = make_engine(pkg, seq, n)
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.search_fuse(refs, nbrs, seq.min_depth, seq.max_depth)
+    total = 0
+    for k in refs:
+        r, s, st = oracle.recon_search_fuse(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, seq.min_depth, seq.max_depth)
+        gr, gs = eng.download_depth(k)
+        assert ((gr > 1e-6) == (r > 1e-6)).all(), "support mask"
+        assert_bit_equal(gr, r, "rho kf %d" % k)
+        assert_bit_equal(gs, s, "sigma kf %d" % k)
+        total += st["fused"]
+    assert total > 100, "scene must exercise the fusion path"
+    eng.close()
+
+
+def test_search_fuse_stats(pkg, oracle, gpu_ok, seq_mid):
+    eng = make_engine(pkg, seq_mid, 7)
+    eng.enable_stats(True)
+    eng.get_stats(reset=True)
+    nb = seq_mid.neighbours(3, 7)
+    eng.search_fuse([3], [nb], seq_mid.min_depth, seq_mid.max_depth)
+    got = eng.get_stats()
+    _, _, ref = oracle.recon_search_fuse(seq_mid.okf[3], [seq_mid.okf[j] for j in nb], None, seq_mid.min_depth,
+                                         seq_mid.max_depth)
+    assert got == ref
+    eng.close()
+
+
+def test_rot_and_params(pkg, oracle, gpu_ok, seq_mid):
+    """non-zero in-plane rotation per neighbour, and non-default gates"""
+    n = 7
+    eng = make_engine(pkg, seq_mid, n)
+    nb = seq_mid.neighbours(4, n)
+    rot = np.float32([0, 2, -3, 10, 355, 180, 44])
+    eng.search_fuse([4], [nb], seq_mid.min_depth, seq_mid.max_depth, rot=[rot])
+    r, s, _ = oracle.recon_search_fuse(seq_mid.okf[4], [seq_mid.okf[j] for j in nb], rot, seq_mid.min_depth, seq_mid.max_depth)
+    gr, gs = eng.download_depth(4)
+    assert_bit_equal(gr, r)
+    assert_bit_equal(gs, s)
+    eng.set_params(lambdaG=12.0, lambdaL=60.0, lambdaTheta=30.0, lambdaN=2, theta_var=0.5)
+    oracle.params.lambdaG, oracle.params.lambdaL, oracle.params.lambdaTheta = 12.0, 60.0, 30.0
+    oracle.params.lambdaN, oracle.params.theta_var = 2, 0.5
+    try:
+        eng.recon([4], [nb], seq_mid.min_depth, seq_mid.max_depth)
+        r, s, _ = oracle.semi_dense_recon(seq_mid.okf[4], [seq_mid.okf[j] for j in nb], None, seq_mid.min_depth,
+                                          seq_mid.max_depth)
+    finally:
+        oracle.lib.pmo_default_params(oracle.params)
+    gr, gs = eng.download_depth(4)
+    assert (gr > 1e-6).sum() > 50
+    assert_bit_equal(gr, r)
+    assert_bit_equal(gs, s)
+    eng.close()
+
+
+def crafted_maps(rng, H, W, density=0.3, zero_sigma_frac=0.1, orphan_sigma_frac=0.1):
+    rho = np.where(rng.random((H, W)) < density, 1.0 + 0.02 * rng.standard_normal((H, W)), 0.0).astype(np.float32)
+    sig = np.where(rho > 0, 0.01 + 0.05 * rng.random((H, W)), 0.0).astype(np.float32)
+    sig[(rng.random((H, W)) < zero_sigma_frac) & (rho > 0)] = 0.0          # supported pixel with sigma 0
+    orphan = (rng.random((H, W)) < orphan_sigma_frac) & (rho == 0)
+    # rho 0 & sigma > 0 next to wide-sigma neighbours: the only inputs for which growing is live
+    sig[orphan] = (1.0 + 2.0 * rng.random((H, W)))[orphan].astype(np.float32)
+    wide = (rng.random((H, W)) < 0.3) & (rho > 0)
+    sig[wide] = (1.0 + 2.0 * rng.random((H, W)))[wide].astype(np.float32)
+    rho[rng.random((H, W)) < 0.01] = np.nan
+    rho[rng.random((H, W)) < 0.01] = -0.5
+    sig[rng.random((H, W)) < 0.005] = np.inf
+    return rho, sig
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (75, 200), (16, 64), (33, 130)])
+def test_intra_check_and_grow_maps(pkg, oracle, gpu_ok, shape):
+    """K2/K3 through the PM.h:85-86 signatures on crafted maps (NaN/Inf/zero-sigma/border cases,
+    and rho=0 & sigma>0 pixels for which IntraKeyFrameDepthGrowing is NOT a no-op, App. A.6)"""
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    eng = pkg.Engine(W, H, 2)
+    for rep in range(3):
+        rho, sig = crafted_maps(rng, H, W, density=[0.3, 0.7, 0.05][rep])
+        grad = (16 * rng.random((H, W))).astype(np.float32)
+        r1, s1 = eng.intra_check_maps(rho, sig)
+        o1, p1 = oracle.intra_check(rho, sig)
+        assert_bit_equal(r1, o1, "check rho")
+        assert_bit_equal(s1, p1, "check sigma")
+        r2, s2 = eng.intra_grow_maps(rho, sig, grad)
+        o2, p2 = oracle.intra_grow(rho, sig, grad)
+        assert_bit_equal(r2, o2, "grow rho")
+        assert_bit_equal(s2, p2, "grow sigma")
+        assert not np.array_equal(o2.view(np.uint32), rho.view(np.uint32)), "growing must be exercised"
+    eng.close()
+
+
+def test_growing_is_noop_on_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
+    """after K1+K2 every rho<1e-6 pixel has sigma 0, so K3 changes nothing"""
+    eng = make_engine(pkg, seq_mid, 7)
+    nb = seq_mid.neighbours(3, 7)
+    eng.search_fuse([3], [nb], seq_mid.min_depth, seq_mid.max_depth)
+    eng.intra_check([3])
+    a = eng.download_depth(3)
+    eng.intra_grow([3])
+    b = eng.download_depth(3)
+    assert_bit_equal(a[0], b[0])
+    assert_bit_equal(a[1], b[1])
+    eng.close()
+
+
+@pytest.mark.parametrize("which,n", [("small", 7), ("mid", 7), ("ragged", 20)])
+def test_full_path_parity(pkg, oracle, gpu_ok, seq_small, seq_mid, seq_ragged, which, n):
+    """SemiDenseRecon -> InterKeyFrameDepthChecking (snapshot) -> UpdateSemiDensePointSet"""
+    seq = dict(small=seq_small, mid=seq_mid, ragged=seq_ragged)[which]
+    eng = make_engine(pkg, seq, n, batch_capacity=3)  # forces several scratch chunks
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    maps = oracle_pipeline(oracle, seq, n)
+    for k in refs:
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, maps["rho"][k], "recon rho kf %d" % k)
+        assert_bit_equal(gs, maps["sigma"][k], "recon sigma kf %d" % k)
+    eng.inter_check(refs, nbrs, commit=False)
+    eng.pointset(refs, source=1)
+    chk, xyz = oracle_inter(oracle, seq, n, maps)
+    kept = 0
+    for k in refs:
+        g = eng.download_checked(k)
+        assert ((g > 1e-6) == (chk[k] > 1e-6)).all()
+        assert_bit_equal(g, chk[k], "checked rho kf %d" % k)
+        assert_bit_equal(eng.download_pointset(k), xyz[k], "xyz kf %d" % k)
+        # sigma is untouched by the inter-keyframe check (PM.cc:764)
+        assert_bit_equal(eng.download_depth(k)[1], maps["sigma"][k])
+        kept += int((g > 1e-6).sum())
+    assert kept > 100
+    eng.close()
+
+
+def test_inter_check_sequential_commit(pkg, oracle, gpu_ok, seq_mid):
+    """the reference's in-place, keyframe-by-keyframe order (PM.cc:262-315): later keyframes see
+    the already-checked maps of earlier ones"""
+    n = 7
+    seq = seq_mid
+    eng = make_engine(pkg, seq, n)
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    maps = oracle_pipeline(oracle, seq, n)
+    rho = {k: maps["rho"][k].copy() for k in refs}
+    for k in refs:
+        eng.inter_check([k], [nbrs[k]], commit=True)
+        rho[k] = oracle.inter_check(seq.okf[k], rho[k], [seq.okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                                    [maps["sigma"][j] for j in nbrs[k]])
+    for k in refs:
+        assert_bit_equal(eng.download_depth(k)[0], rho[k], "sequential inter-check kf %d" % k)
+    eng.close()
+
+
+def test_inter_check_crafted(pkg, oracle, gpu_ok, seq_small):
+    """crafted neighbour maps: NaN / negative / zero-sigma taps, projections leaving the image"""
+    n = 7
+    seq = seq_small
+    eng = make_engine(pkg, seq, n)
+    rng = np.random.default_rng(9)
+    rho, sig = {}, {}
+    for k in range(seq.n_kf):
+        rho[k], sig[k] = crafted_maps(rng, seq.H, seq.W, density=0.8, orphan_sigma_frac=0.0)
+        rho[k][rho[k] > 0] = (seq.gt[k] * (1 + 0.01 * rng.standard_normal((seq.H, seq.W))).astype(np.float32))[rho[k] > 0]
+        eng.upload_depth(k, rho[k], sig[k])
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    n_kept = 0
+    for k in refs:
+        ref = oracle.inter_check(seq.okf[k], rho[k], [seq.okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                                 [sig[j] for j in nbrs[k]])
+        got = eng.download_checked(k)
+        assert_bit_equal(got, ref, "crafted inter-check kf %d" % k)
+        assert_bit_equal(eng.download_pointset(k), oracle.pointset(seq.okf[k], ref), "crafted xyz")
+        n_kept += int((ref > 1e-6).sum())
+    assert n_kept > 200
+    eng.close()
+
+
+def test_pointset_pose_update(pkg, oracle, gpu_ok, seq_small):
+    """UpdateAllSemiDensePointSet: re-project after kf->poseChanged (PM.cc:321-334)"""
+    seq = seq_small
+    eng = make_engine(pkg, seq, 7)
+    rng = np.random.default_rng(4)
+    rho = np.where(rng.random((seq.H, seq.W)) < 0.5, 0.5 + rng.random((seq.H, seq.W)), 0).astype(np.float32)
+    eng.upload_depth(2, rho, np.zeros_like(rho))
+    eng.pointset([2], source=0)
+    assert_bit_equal(eng.download_pointset(2), oracle.pointset(seq.okf[2], rho))
+    T2 = seq.Tcw[5]
+    eng.set_pose(2, T2)
+    eng.pointset([2], source=0)
+    kf = oracle.keyframe(seq.im[2], seq.grad[2], seq.theta[2], seq.istd[2], seq.K, T2)
+    assert_bit_equal(eng.download_pointset(2), oracle.pointset(kf, rho))
+    eng.close()
+
+
+def test_batch_invariance(pkg, oracle, gpu_ok, seq_mid):
+    """a keyframe's result does not depend on what else is in the batch or on slot numbering"""
+    n = 7
+    seq = seq_mid
+    eng = make_engine(pkg, seq, n)
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    all_maps = [eng.download_depth(k) for k in refs]
+    eng.recon([5], [nbrs[5]], seq.min_depth, seq.max_depth)
+    one = eng.download_depth(5)
+    assert_bit_equal(one[0], all_maps[5][0])
+    assert_bit_equal(one[1], all_maps[5][1])
+    eng.recon(refs[::-1], nbrs[::-1], seq.min_depth, seq.max_depth)
+    for k in refs:
+        m = eng.download_depth(k)
+        assert_bit_equal(m[0], all_maps[k][0])
+    eng.close()
+
+
+def test_noise_images(pkg, oracle, gpu_ok):
+    """adversarial i.i.d. uniform images: nearly nothing fuses, scan-only path"""
+    seq = Sequence(pkg, oracle, 96, 64, 8, 0x5EED0A04, noise=True)
+    eng = make_engine(pkg, seq, 7)
+    refs = [2, 3]
+    nbrs = [seq.neighbours(k, 7) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    for i, k in enumerate(refs):
+        r, s, _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[i]], None, seq.min_depth, seq.max_depth)
+        g = eng.download_depth(k)
+        assert_bit_equal(g[0], r)
+        assert_bit_equal(g[1], s)
+    eng.close()
+
+
+def test_error_behaviour(pkg, gpu_ok):
+    eng = pkg.Engine(64, 48, 4, max_neighbours=3)
+    with pytest.raises(pkg.SdmError) as e:
+        eng.recon([0], [[1, 2, 3]], 1.25, 0.83)
+    assert e.value.code == 4  # SDM_ESTATE: nothing uploaded
+    with pytest.raises(pkg.SdmError) as e:
+        eng.download_depth(9)
+    assert e.value.code == 1
+    with pytest.raises(pkg.SdmError):
+        pkg.Engine(64, 48, 4, max_neighbours=65)
+    with pytest.raises(pkg.SdmError):
+        pkg.Engine(64, 48, 4, device=99)
+    z = np.zeros((48, 64), np.uint8)
+    K = np.float32([50, 50, 32, 24])
+    T = np.eye(4, dtype=np.float32)[:3]
+    for k in range(4):
+        eng.upload_image(k, z, K, T)
+    with pytest.raises(pkg.SdmError) as e:
+        eng.recon([0], [[1, 2, 3, 0]], 1.25, 0.83)  # n > max_neighbours
+    assert e.value.code == 1
+    eng.recon([0], [[1, 2, 3]], 1.25, 0.83)  # empty image: runs, yields an all-zero map
+    r, s = eng.download_depth(0)
+    assert not r.any() and not s.any()
+    with pytest.raises(pkg.SdmError) as e:
+        eng.download_checked(0)
+    assert e.value.code == 4
+    eng.close()
