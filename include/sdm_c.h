@@ -167,6 +167,10 @@ int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
 int sdm_enable_timing(sdm_ctx *ctx, int on);
 int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long launches[SDM_NUM_STAGES],
                    int reset);
+/* device arithmetic self-tests: out[0] = mismatches (must be 0), out[1] = auxiliary count.
+ * which 0: reciprocal+FMA division by theta_var vs plain division over all 2^32 float inputs;
+ * which 1: reciprocal-prefiltered ChiTest vs the exact ChiTest around the 5.99 threshold. */
+int sdm_selftest(sdm_ctx *ctx, int which, unsigned long long out[2]);
 /* name of the device the context runs on, e.g. "gfx950" */
 const char *sdm_device_arch(sdm_ctx *ctx);
 

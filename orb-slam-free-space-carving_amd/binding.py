@@ -80,6 +80,7 @@ SYMBOLS = [
     ("sdm_median_rot_in_plane", C.c_float, [_ip, _f32p, C.c_int, _ip, _f32p, C.c_int]),
     ("sdm_enable_stats", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_stats", C.c_int, [_ctx, C.POINTER(Stats), C.c_int]),
+    ("sdm_selftest", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_ulonglong)]),
     ("sdm_enable_timing", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_timing", C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     ("sdm_device_arch", C.c_char_p, [_ctx]),
@@ -336,6 +337,11 @@ class Engine:
     # -- instrumentation ---------------------------------------------------------------------------------
     def enable_stats(self, on=True):
         self._check(self.lib.sdm_enable_stats(self.ctx, 1 if on else 0))
+
+    def selftest(self, which):
+        out = (C.c_ulonglong * 2)()
+        self._check(self.lib.sdm_selftest(self.ctx, which, out))
+        return int(out[0]), int(out[1])
 
     STAGES = ("search_fuse", "intra", "inter", "pointset")
 

@@ -27,7 +27,7 @@ struct RefConst {  // per reference keyframe of a batch
     int slot;
     float fx, fy, cx, cy;
     float mind, maxd;  // min_depth / max_depth as named at PM.cc:381-382
-    int pad;
+    int act_count;     // entries in the keyframe's active-pixel list (PM.cc:201 gate)
 };
 
 struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of the per-pixel code
@@ -47,7 +47,24 @@ struct DevParams {  // sdm_params + host-precomputed (1/THETA), PM.cc:455-456
     int lambdaN;
     double theta_var;
     double inv_theta;
+    int fast_theta_div;  // x/theta_var via reciprocal + FMA correction (exhaustively verified for 0.23)
+    int pad;
 };
+
+// x / d for a double x that was widened from a non-negative float, d = theta_var, r = RN(1/d).
+// Two FMA residual corrections (Markstein): q2 == RN(x/d).  tests/test_gpu_arith.py checks it
+// against the hardware-division sequence for ALL 2^32 float inputs at d = 0.23; for any other
+// theta_var the engine keeps the plain division.
+__device__ __forceinline__ double div_theta(double x, const double d, const double r, const bool fast)
+{
+    if (!fast) return x / d;
+    double q0 = x * r;
+    double e0 = __builtin_fma(-q0, d, x);
+    double q1 = __builtin_fma(e0, r, q0);
+    double e1 = __builtin_fma(-q1, d, x);
+    double q2 = __builtin_fma(e1, r, q1);
+    return (x < 1.0e300) ? q2 : q0;  // +inf -> +inf, NaN -> NaN (no residuals through inf - inf)
+}
 
 // ---- cv::fastAtan2 (PM.cc:414): OpenCV 3.x atan_f32 polynomial, degrees [0,360) ------------------
 __host__ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -200,6 +217,8 @@ __device__ __forceinline__ void search_range(float fx, float cx, float rxxp, flo
     if (umax > cols) umax = cols;
 }
 
+constexpr int SCAN_UNROLL = 4;
+
 struct SearchStats {
     unsigned long long searches, candidates, gate_pass;
 };
@@ -237,7 +256,8 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     search_range(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, umin, umax);  // PM.cc:404
     if (umin != umin || umax != umax) return false;
 
-    float th_line = fast_atan2_deg(-a / b, 1.0f);  // PM.cc:414 (loop invariant)
+    // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
+    float th_line = fast_atan2_deg(-ab, 1.0f);
     float ang_pi_rot = th_pi + pc->rot;            // PM.cc:424-426
     if (ang_pi_rot >= 360) ang_pi_rot -= 360;
     if (ang_pi_rot < 0) ang_pi_rot += 360;
@@ -249,34 +269,56 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     int hi = (int)floorf(umax);
     if (hi > W - 1) hi = W - 1;
     const float hlim = (float)(H - 1);
-    for (int uj = lo; uj <= hi; uj++) {  // PM.cc:405
-        if (STATS) st->candidates++;
-        float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
-        if (!(yf >= 1.0f && yf < hlim)) continue;
-        int vj = (int)yf;
-        float4 r = nrec[vj * W + uj];
-        if (r.x < prm.lambdaG) continue;  // PM.cc:411
-        float ang_diff = r.y - th_line;   // PM.cc:415-421
-        if (ang_diff >= 360) ang_diff -= 360;
-        if (ang_diff < 0) ang_diff += 360;
-        if (ang_diff > 180) ang_diff = 360 - ang_diff;
-        if (ang_diff > 90) ang_diff = 180 - ang_diff;
-        if (ang_diff > prm.lambdaL) continue;
-        float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
-        if (th_diff >= 360) th_diff -= 360;
-        if (th_diff < 0) th_diff += 360;
-        if (th_diff > 180) th_diff = 360 - th_diff;
-        if (th_diff > prm.lambdaTheta) continue;
-        if (STATS) st->gate_pass++;
-        float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
-        float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
-        float pe2 = pe * pe, ge2 = ge * ge;
-        float err = (float)((double)pe2 + (double)ge2 / prm.theta_var);  // PM.cc:436
-        if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
-            best_pixel = uj;
-            old_err = err;
-            best_pe = pe;
-            best_ge = ge;
+    // PM.cc:405 scan.  Candidates are visited in increasing uj exactly as the reference does (the
+    // strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four
+    // at a time so that four independent 16-byte gathers are in flight per lane.
+    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL) {
+        float yfs[SCAN_UNROLL];
+        float4 rs[SCAN_UNROLL];
+        bool vs[SCAN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+            int uj = u0 + k;
+            float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
+            bool v = (uj <= hi) && (yf >= 1.0f && yf < hlim);
+            int vj = v ? (int)yf : 1;
+            int uc = v ? uj : lo;
+            yfs[k] = yf;
+            vs[k] = v;
+            rs[k] = nrec[vj * W + uc];
+        }
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+            const int uj = u0 + k;
+            if (STATS && uj <= hi) st->candidates++;
+            if (!vs[k]) continue;
+            const float yf = yfs[k];
+            const int vj = (int)yf;
+            const float4 r = rs[k];
+            if (r.x < prm.lambdaG) continue;  // PM.cc:411
+            float ang_diff = r.y - th_line;   // PM.cc:415-421
+            if (ang_diff >= 360) ang_diff -= 360;
+            if (ang_diff < 0) ang_diff += 360;
+            if (ang_diff > 180) ang_diff = 360 - ang_diff;
+            if (ang_diff > 90) ang_diff = 180 - ang_diff;
+            if (ang_diff > prm.lambdaL) continue;
+            float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
+            if (th_diff >= 360) th_diff -= 360;
+            if (th_diff < 0) th_diff += 360;
+            if (th_diff > 180) th_diff = 360 - th_diff;
+            if (th_diff > prm.lambdaTheta) continue;
+            if (STATS) st->gate_pass++;
+            float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
+            float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
+            float pe2 = pe * pe, ge2 = ge * ge;
+            float err = (float)((double)pe2 +
+                                div_theta((double)ge2, prm.theta_var, prm.inv_theta, prm.fast_theta_div));  // PM.cc:436
+            if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
+                best_pixel = uj;
+                old_err = err;
+                best_pe = pe;
+                best_ge = ge;
+            }
         }
     }
     if (!(old_err < 1000000.0f)) return false;  // PM.cc:446
@@ -333,6 +375,30 @@ __device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, f
 }
 
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.
+//
+// The N^2 ChiTest divisions dominate a naive port.  Each decision "chi < 5.99" is first tried with
+// reciprocals (v_rcp_f32, 1 ulp): chi~ = num*ra + num*rb differs from the reference's
+// num/sa^2 + num/sb^2 by a relative 2^-20 at most, so outside the band 5.99*(1 +- 2^-14) the
+// decision is already certain; only inside the band (or for zero / denormal / Inf / NaN sigmas,
+// whose reciprocal is forced to NaN) is the exact chi_test evaluated.  Decisions are therefore
+// bit-identical to the reference arithmetic.
+__device__ __forceinline__ float safe_rcp_sq(float s)
+{
+    float s2 = s * s;
+    bool ok = (s2 >= 1.0e-30f) && (s2 <= 1.0e30f);
+    return ok ? __builtin_amdgcn_rcpf(s2) : __builtin_nanf("");
+}
+
+__device__ __forceinline__ bool chi_test_fast(float a, float b, float sa, float sb, float ra, float rb)
+{
+    float d = a - b;
+    float num = d * d;
+    float approx = num * ra + num * rb;
+    if (approx < 5.9896f) return true;    // 5.99 * (1 - 2^-14)
+    if (approx > 5.9904f) return false;   // 5.99 * (1 + 2^-14)
+    return chi_test(a, b, sa, sb);        // band, or NaN from unsafe operands
+}
+
 __device__ __forceinline__ bool fuse_column(const float2* hyp, int stride, int nh, int lambdaN,
                                             float& rho_o, float& sigma_o)
 {
@@ -340,10 +406,11 @@ __device__ __forceinline__ bool fuse_column(const float2* hyp, int stride, int n
     int best = 0;
     for (int a = 0; a < nh; a++) {
         float2 ha = hyp[a * stride];
+        const float ra = safe_rcp_sq(ha.y);
         unsigned long long m = 0;
         for (int b = 0; b < nh; b++) {
             float2 hb = hyp[b * stride];
-            if (chi_test(ha.x, hb.x, ha.y, hb.y)) m |= 1ull << b;
+            if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, safe_rcp_sq(hb.y))) m |= 1ull << b;
         }
         int cnt = __popcll(m);
         if (cnt > best) {  // strict: first largest set wins, PM.cc:616

@@ -59,6 +59,10 @@ struct sdm_ctx {
     KfMeta* d_meta = nullptr;
     std::vector<KfMeta> h_meta;
     std::vector<char> has_depth, has_chk;
+    unsigned* d_act = nullptr;     // [max_keyframes][P] active-pixel lists (y<<16|x), raster order
+    int* d_act_count = nullptr;    // [max_keyframes]
+    std::vector<int> h_act_count;  // host mirror
+    std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
 
     // staging for one keyframe
     uint8_t* d_im = nullptr;
@@ -107,6 +111,21 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.lambdaN = c->prm.lambdaN;
     c->dprm.theta_var = c->prm.theta_var;
     c->dprm.inv_theta = 1 / c->prm.theta_var;  // (1/THETA), PM.cc:455
+    c->dprm.fast_theta_div = (c->prm.theta_var == 0.23) ? 1 : 0;
+    c->dprm.pad = 0;
+}
+
+// (re)build the active-pixel list of a slot for the current lambdaG; reads the count back
+int build_active(sdm_ctx* c, int slot)
+{
+    hipLaunchKernelGGL(k_build_active, dim3(1), dim3(ACT_BLOCK), 0, c->stream, c->rec + (long long)slot * c->P, c->W,
+                       c->H, c->dprm.lambdaG, c->d_act + (long long)slot * c->P, c->d_act_count + slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&c->h_act_count[slot], c->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->act_lambdaG[slot] = c->dprm.lambdaG;
+    return SDM_OK;
 }
 
 int check_slot(sdm_ctx* c, int slot, bool need_upload)
@@ -170,6 +189,9 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     int rc = wait_tables(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    for (int r = 0; r < n_ref; r++)  // lists follow lambdaG (sdm_set_params)
+        if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG))
+            if ((rc = build_active(c, ref_slots[r]))) return rc;
     memcpy(c->h_ref_slots, ref_slots, sizeof(int) * n_ref);
     HIP_TRY(hipMemcpyAsync(c->d_ref_slots, c->h_ref_slots, sizeof(int) * n_ref, hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
@@ -188,8 +210,8 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
         HIP_TRY(hipMemcpyAsync(c->d_mind, c->h_mind, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_maxd, c->h_maxd, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_pair_setup, dim3(blocks_for((long long)np)), dim3(BLOCK), 0, c->stream, c->d_meta,
-                           c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, n_ref, n, c->d_refs,
-                           c->d_pairs);
+                           c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, n_ref, n,
+                           c->d_refs, c->d_pairs);
         HIP_TRY(hipGetLastError());
     }
     return SDM_OK;
@@ -242,7 +264,7 @@ int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
     HIP_TRY(hipMemcpyAsync(&c->h_meta[slot].I_stddev, &c->d_meta[slot].I_stddev, sizeof(float), hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return SDM_OK;
+    return build_active(c, slot);
 }
 
 template <typename T>
@@ -330,6 +352,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->h_meta.assign(K, KfMeta{});
     c->has_depth.assign(K, 0);
     c->has_chk.assign(K, 0);
+    c->h_act_count.assign(K, 0);
+    c->act_lambdaG.assign(K, std::nanf(""));
 
     int rc = SDM_OK;
     auto bail = [&](int code) {
@@ -357,6 +381,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if (cfg->with_pointset)
         if ((rc = dev_alloc(&c->xyz, (size_t)c->P * 3 * K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_meta, (size_t)K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_act, (size_t)c->P * K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_act_count, (size_t)K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
@@ -380,6 +406,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->pool, 0, sizeof(float2) * c->P * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->chk, 0, sizeof(float) * c->P * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_meta, 0, sizeof(KfMeta) * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_act_count, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -407,6 +434,8 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->chk);
     (void)hipFree(c->xyz);
     (void)hipFree(c->d_meta);
+    (void)hipFree(c->d_act);
+    (void)hipFree(c->d_act_count);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
@@ -483,7 +512,8 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     fill_meta(m, K, Tcw);
     m.I_stddev = I_stddev;
     m.uploaded = 1;
-    return push_meta(c, slot);
+    if ((rc = push_meta(c, slot))) return rc;
+    return build_active(c, slot);
 }
 
 int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], const float Tcw[12])
@@ -539,17 +569,23 @@ int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* t
 }
 
 // ---- K1..K3 ----------------------------------------------------------------------------------------------------
-static int launch_search_fuse(sdm_ctx* c, int n_ref, int n)
+static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots)
 {
     StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);
+    hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                       c->d_ref_slots, n_ref);
+    HIP_TRY(hipGetLastError());
+    int max_chunks = 0;
+    for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
+    if (max_chunks == 0) return SDM_OK;  // no pixel passes the gradient gate: the maps stay zero
     const size_t lds = search_lds_bytes(n);
-    const int grid = grid_blocks(c->geom, n_ref);
+    const int grid = 8 * ((max_chunks + 7) / 8) * n_ref;
     if (c->stats_on)
         hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
-                           c->d_pairs, n_ref, n, c->geom, c->dprm, c->pool, c->d_stats);
+                           c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
     else
         hipLaunchKernelGGL(k_search_fuse<false>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
-                           c->d_pairs, n_ref, n, c->geom, c->dprm, c->pool, c->d_stats);
+                           c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
     HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
@@ -562,7 +598,7 @@ int sdm_search_fuse(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
     if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
     if (rc) return rc;
-    if ((rc = launch_search_fuse(c, n_ref, n))) return rc;
+    if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;
     for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;
     return tables_staged(c);
 }
@@ -654,7 +690,7 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
     if (rc) return rc;
-    if ((rc = launch_search_fuse(c, n_ref, n))) return rc;            // PM.cc:197-231
+    if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
     if ((rc = run_intra(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
     for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244
     return tables_staged(c);
@@ -909,6 +945,27 @@ int sdm_enable_stats(sdm_ctx* c, int on)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     c->stats_on = on != 0;
+    return SDM_OK;
+}
+
+int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
+{
+    if (!c || !out) return fail(SDM_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    if (which == 0) {
+        hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(BLOCK), 0, c->stream, c->dprm.theta_var, c->dprm.inv_theta,
+                           c->d_stats + 5);
+    } else if (which == 1) {
+        hipLaunchKernelGGL(k_selftest_chi, dim3(1024), dim3(BLOCK), 0, c->stream, 1024, c->d_stats + 5,
+                           c->d_stats + 6);
+    } else {
+        return fail(SDM_EINVAL, "unknown selftest");
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->d_stats + 5, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
     return SDM_OK;
 }
 

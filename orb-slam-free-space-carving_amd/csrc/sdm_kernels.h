@@ -159,7 +159,8 @@ __global__ __launch_bounds__(BLOCK) void k_unpack(const float4* __restrict__ rec
 // device from the resident keyframe metadata, so a batch needs only slot indices from the host.
 __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restrict__ ref_slots,
                              const int* __restrict__ nbr_slots, const float* __restrict__ rot,
-                             const float* __restrict__ mind, const float* __restrict__ maxd, int n_ref, int n,
+                             const float* __restrict__ mind, const float* __restrict__ maxd,
+                             const int* __restrict__ act_counts, int n_ref, int n,
                              RefConst* __restrict__ refs, PairConst* __restrict__ pairs)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,96 +188,134 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
         rc.cy = m1.cy;
         rc.mind = mind ? mind[r] : 0.f;
         rc.maxd = maxd ? maxd[r] : 0.f;
-        rc.pad = 0;
+        rc.act_count = act_counts[ref_slots[r]];
         refs[r] = rc;
     }
 }
 
+// ---- active-pixel lists ------------------------------------------------------------------------------------
+// The reference skips every pixel with GradImg < lambdaG (PM.cc:201), ~80 % of an image, and every
+// later stage only ever touches the survivors.  That set depends on the keyframe's own image only,
+// so it is built ONCE when the keyframe is uploaded: act[] holds (y << 16 | x) of the inset pixels
+// that pass the gate, in raster order (one workgroup per keyframe, deterministic).
+constexpr int ACT_BLOCK = 1024;
+__global__ __launch_bounds__(ACT_BLOCK) void k_build_active(const float4* __restrict__ rec, int W, int H,
+                                                            float lambdaG, unsigned* __restrict__ act,
+                                                            int* __restrict__ count)
+{
+    __shared__ int wsum[ACT_BLOCK / 64];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const int P = W * H;
+    for (int start = 0; start < P; start += ACT_BLOCK) {
+        int idx = start + tid;
+        bool f = false;
+        int x = 0, y = 0;
+        if (idx < P) {
+            y = idx / W;
+            x = idx - y * W;
+            if (x >= 2 && x < W - 2 && y >= 2 && y < H - 2) f = !(rec[idx].x < lambdaG);  // PM.cc:198-201
+        }
+        unsigned long long m = __ballot(f);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (f) act[off + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)y << 16) | (unsigned)x;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < ACT_BLOCK / 64; w++) tot += wsum[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
+// zero the depth maps of a batch's reference keyframes (a fresh depth_map_/depth_sigma_)
+__global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, long long plane,
+                                                     const int* __restrict__ slots, int n_ref)
+{
+    long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= plane * n_ref) return;
+    int r = (int)(idx / plane);
+    long long p = idx - (long long)r * plane;
+    pool[(long long)slots[r] * plane + p] = make_float2(0.f, 0.f);
+}
+
 // ---- K1: epipolar search + hypothesis fusion, PM.cc:197-231 --------------------------------------------
+// One thread per ACTIVE pixel of a reference keyframe (256 consecutive list entries per
+// workgroup); the neighbour index j is looped uniformly, so the per-(ref,nbr) constants live in
+// scalar registers and adjacent lanes scan adjacent epipolar segments of the same neighbour.
 // Dynamic LDS: float2 hyp[n][256] -- thread-private hypothesis columns (depth_ho of PM.cc:204).
+// The map was zeroed by k_zero_maps; only fused pixels are written (PM.cc:224-227).
 template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict__ rec, long long plane,
                                                        const RefConst* __restrict__ refs,
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
-                                                       TileGeom g, DevParams prm, float2* __restrict__ pool,
+                                                       int W, int H, int max_chunks, DevParams prm,
+                                                       const unsigned* __restrict__ act, float2* __restrict__ pool,
                                                        unsigned long long* __restrict__ stats)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* hyp = reinterpret_cast<float2*>(smem_raw);
-    __shared__ float2 outv[TILE_PX];
-    __shared__ unsigned short act[TILE_PX];
-    __shared__ int wsum[16];
 
-    int ref, tx0, ty0;
-    if (!decode_block(g, n_ref, ref, tx0, ty0)) return;
-    const int tid = threadIdx.x;
-    const int W = g.W, H = g.H;
+    // XCD-aware decode: chunk c of every reference keyframe runs on XCD c % 8
+    const int b = blockIdx.x;
+    const int cpx = (max_chunks + 7) >> 3;
+    const int i8 = b >> 3;
+    const int ref = i8 / cpx;
+    const int chunk = (i8 - ref * cpx) * 8 + (b & 7);
+    if (ref >= n_ref) return;
     const RefConst rc = refs[ref];
+    const int tid = threadIdx.x;
+    const int t = chunk * BLOCK + tid;
+    if (chunk * BLOCK >= rc.act_count) return;
+    const bool on = t < rc.act_count;
     const float4* __restrict__ rrec = rec + (long long)rc.slot * plane;
 
-    bool f[PX_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < PX_PER_THREAD; i++) {
-        int L = i * BLOCK + tid;
-        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
-        bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);  // PM.cc:198-199
-        float gr = inset ? rrec[y * W + x].x : 0.0f;
-        f[i] = inset && !(gr < prm.lambdaG);  // PM.cc:201
-        outv[L] = make_float2(0.f, 0.f);
+    int x = 2, y = 2;
+    float pixel = 0.f, grad1 = 0.f, th_pi = 0.f, xp0 = 0.f, xp1 = 0.f;
+    if (on) {
+        unsigned xy = act[(long long)rc.slot * plane + t];
+        x = (int)(xy & 0xffffu);
+        y = (int)(xy >> 16);
+        float4 r = rrec[y * W + x];
+        pixel = (float)(int)(__float_as_uint(r.w) & 0xffu);  // PM.cc:202
+        grad1 = r.x;
+        th_pi = r.y;                       // PM.cc:214
+        xp0 = ((float)x - rc.cx) / rc.fx;  // PM.cc:862
+        xp1 = ((float)y - rc.cy) / rc.fy;
     }
-    const int nAct = block_compact(f, act, wsum);
-    __syncthreads();
-
     SearchStats st = {0, 0, 0};
-    unsigned long long n_hyp = 0, n_fused = 0;
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
-    for (int base = 0; base < nAct; base += BLOCK) {
-        const int t = base + tid;
-        const bool on = t < nAct;
-        const int L = on ? act[t] : 0;
-        const int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
-        float pixel = 0.f, grad1 = 0.f, th_pi = 0.f, xp0 = 0.f, xp1 = 0.f;
+    int nh = 0;
+    for (int j = 0; j < n; j++) {
+        const PairConst* __restrict__ pc = pcs + j;
+        const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
         if (on) {
-            float4 r = rrec[y * W + x];
-            pixel = (float)(int)(__float_as_uint(r.w) & 0xffu);  // PM.cc:202
-            grad1 = r.x;
-            th_pi = r.y;                    // PM.cc:214
-            xp0 = ((float)x - rc.cx) / rc.fx;  // PM.cc:862
-            xp1 = ((float)y - rc.cy) / rc.fy;
-        }
-        int nh = 0;
-        for (int j = 0; j < n; j++) {
-            const PairConst* __restrict__ pc = pcs + j;
-            const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
-            if (on) {
-                float rho, sigma, bu, bv;
-                bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0,
-                                                 xp1, rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
-                if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
-                    hyp[nh * BLOCK + tid] = make_float2(rho, sigma);
-                    nh++;
-                }
-            }
-        }
-        if (STATS) n_hyp += (unsigned long long)nh;
-        if (on && nh > prm.lambdaN) {  // PM.cc:221
-            float rho, sigma;
-            if (fuse_column(hyp + tid, BLOCK, nh, prm.lambdaN, rho, sigma)) {  // PM.cc:223-227
-                outv[L] = make_float2(rho, sigma);
-                if (STATS) n_fused++;
+            float rho, sigma, bu, bv;
+            bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0, xp1,
+                                             rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
+            if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
+                hyp[nh * BLOCK + tid] = make_float2(rho, sigma);
+                nh++;
             }
         }
     }
-    __syncthreads();
-    float2* __restrict__ out = pool + (long long)rc.slot * plane;
-#pragma unroll
-    for (int i = 0; i < PX_PER_THREAD; i++) {
-        int L = i * BLOCK + tid;
-        int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
-        if (x < W && y < H) out[y * W + x] = outv[L];
+    unsigned long long n_fused = 0;
+    if (on && nh > prm.lambdaN) {  // PM.cc:221
+        float rho, sigma;
+        if (fuse_column(hyp + tid, BLOCK, nh, prm.lambdaN, rho, sigma)) {  // PM.cc:223-227
+            pool[(long long)rc.slot * plane + y * W + x] = make_float2(rho, sigma);
+            n_fused = 1;
+        }
     }
     if (STATS) {
-        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass, n_hyp, n_fused};
+        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass, (unsigned long long)nh, n_fused};
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             unsigned long long s = v[k];
@@ -620,6 +659,72 @@ __global__ void k_fuse_px(const float2* __restrict__ hyp, int n, int lambdaN, fl
     out[0] = ok ? rho : 0.f;
     out[1] = ok ? sigma : 0.f;
     out[2] = ok ? 1.f : 0.f;
+}
+
+// ---- arithmetic self-tests (tests/test_gpu_arith.py) ---------------------------------------------------------
+// which = 0: div_theta fast path vs the plain double division for ALL 2^32 float bit patterns.
+__global__ __launch_bounds__(BLOCK) void k_selftest_div(double d, double r, unsigned long long* __restrict__ bad)
+{
+    unsigned long long cnt = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += stride) {
+        float f = __uint_as_float((unsigned)i);
+        double x = (double)(f * f);  // the operand shape of PM.cc:436 (a squared float), plus...
+        double a = div_theta(x, d, r, true), b = x / d;
+        if (!(a == b || (a != a && b != b))) cnt++;
+        double x2 = (double)fabsf(f);  // ...every non-negative float itself
+        a = div_theta(x2, d, r, true);
+        b = x2 / d;
+        if (!(a == b || (a != a && b != b))) cnt++;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(bad, cnt);
+}
+
+// which = 1: chi_test_fast vs chi_test on pseudo-random operands concentrated around the 5.99
+// threshold, plus special values (0, denormal, Inf, NaN sigmas).
+__device__ __forceinline__ unsigned xs32(unsigned& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+__global__ __launch_bounds__(BLOCK) void k_selftest_chi(int iters, unsigned long long* __restrict__ bad,
+                                                        unsigned long long* __restrict__ inband)
+{
+    unsigned s = 0x9E3779B9u * (blockIdx.x * BLOCK + threadIdx.x + 1);
+    unsigned long long cnt = 0, band = 0;
+    const float specials[8] = {0.f, 1e-41f, 1e-20f, 1e20f, __builtin_inff(), __builtin_nanf(""), 1e-16f, 3e15f};
+    for (int i = 0; i < iters; i++) {
+        float u1 = (xs32(s) >> 8) * (1.0f / 16777216.0f), u2 = (xs32(s) >> 8) * (1.0f / 16777216.0f);
+        float u3 = (xs32(s) >> 8) * (1.0f / 16777216.0f), u4 = (xs32(s) >> 8) * (1.0f / 16777216.0f);
+        float sa = 0.001f + u1, sb = 0.001f + u2;
+        float a = 1.0f + u3;
+        // choose b so that chi lands within ~1e-6 relative of 5.99 half of the time
+        float target = (i & 1) ? 5.99f * (1.0f + (u4 - 0.5f) * 4e-6f) : 12.0f * u4;
+        float k = 1.0f / (sa * sa) + 1.0f / (sb * sb);
+        float b = a + sqrtf(target / k);
+        unsigned pick = xs32(s);
+        if ((pick & 1023u) == 0) sa = specials[(pick >> 10) & 7];
+        if ((pick & 1023u) == 1) sb = specials[(pick >> 10) & 7];
+        if ((pick & 1023u) == 2) b = a;
+        if ((pick & 1023u) == 3) b = specials[(pick >> 10) & 7];
+        bool e = chi_test(a, b, sa, sb);
+        bool f = chi_test_fast(a, b, sa, sb, safe_rcp_sq(sa), safe_rcp_sq(sb));
+        if (e != f) cnt++;
+        float d = a - b, num = d * d;
+        float chi = num / (sa * sa) + num / (sb * sb);
+        if (chi > 5.9896f && chi < 5.9904f) band++;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        band += __shfl_down(band, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        if (band) atomicAdd(inband, band);
+    }
 }
 
 }  // namespace sdm
