@@ -33,7 +33,8 @@ class Stats(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libsdm_hip.so")
+    # SDM_LIB_PATH: A/B a differently-built engine (kernel experiments); still a HIP library
+    return os.environ.get("SDM_LIB_PATH") or os.path.join(_HERE, "lib", "libsdm_hip.so")
 
 
 _lib = None

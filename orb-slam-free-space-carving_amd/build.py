@@ -4,7 +4,9 @@
   lib/libsdm_pm.so   C++ ProbabilityMapping class mirror (include/sdm/ProbabilityMapping.h)
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: the reference's float /
-double promotion pattern must not be fused into FMAs.
+double promotion pattern must not be fused into FMAs.  -fno-slp-vectorize
+keeps hipcc from packing adjacent scalar f32 ops into v_pk_*_f32, which are slower than the two
+scalar instructions on gfx950 (measured: K1 1.99 -> 1.89 ms).
 """
 import os
 import subprocess
@@ -14,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib")
 ARCH = "gfx950"
-COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 

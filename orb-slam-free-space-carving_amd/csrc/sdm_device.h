@@ -217,11 +217,42 @@ __device__ __forceinline__ void search_range(float fx, float cx, float rxxp, flo
     if (umax > cols) umax = cols;
 }
 
-constexpr int SCAN_UNROLL = 4;
+#ifndef SDM_BRANCHFREE_GATES
+#define SDM_BRANCHFREE_GATES 0
+#endif
+#ifndef SDM_SCAN_UNROLL
+#define SDM_SCAN_UNROLL 4
+#endif
+constexpr int SCAN_UNROLL = SDM_SCAN_UNROLL;
 
 struct SearchStats {
     unsigned long long searches, candidates, gate_pass;
 };
+
+// cv::fastAtan2(y, 1.0f) (PM.cc:414): fast_atan2_deg specialised for x == 1.  With ax = 1 the
+// first branch divides by 1.0f + (float)DBL_EPSILON == 1.0f, i.e. c == ay exactly, so the common
+// |a/b| <= 1 case needs no division; results are bit-identical to fast_atan2_deg(y, 1.0f).
+__device__ __forceinline__ float fast_atan2_deg_x1(float y)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    float ay = fabsf(y);
+    float a, c, c2;
+    if (1.0f >= ay) {
+        c = ay;
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = 1.0f / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (y < 0) a = 360.f - a;
+    return a;
+}
 
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
 // nrec: the neighbour keyframe's record plane.  Returns true iff a hypothesis was produced
@@ -245,8 +276,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float b = (float)x * F[1] + (float)y * F[4] + F[7];
     float c = (float)x * F[2] + (float)y * F[5] + F[8];
     float ab = a / b;
-    if (ab < -4 || ab > 4) return false;  // PM.cc:393
-    if (ab != ab) return false;
+    if (!(ab >= -4 && ab <= 4)) return false;  // PM.cc:393; a NaN line yields no hypothesis
     float cb = c / b;
 
     float rxxp = row_dot_xp(pc->R + 0, xp0, xp1);
@@ -254,11 +284,11 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float tx = pc->t[0], tz = pc->t[2];
     float umin, umax;
     search_range(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, umin, umax);  // PM.cc:404
-    if (umin != umin || umax != umax) return false;
+    if (!(umin == umin && umax == umax)) return false;
 
     // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
-    float th_line = fast_atan2_deg(-ab, 1.0f);
-    float ang_pi_rot = th_pi + pc->rot;            // PM.cc:424-426
+    float th_line = fast_atan2_deg_x1(-ab);
+    float ang_pi_rot = th_pi + pc->rot;  // PM.cc:424-426
     if (ang_pi_rot >= 360) ang_pi_rot -= 360;
     if (ang_pi_rot < 0) ang_pi_rot += 360;
 
@@ -268,35 +298,52 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     int lo = (int)ceilf(umin);
     int hi = (int)floorf(umax);
     if (hi > W - 1) hi = W - 1;
-    const float hlim = (float)(H - 1);
+    const float hlim = (float)(H - 1), hlim2 = (float)(H - 2);
+    const char* __restrict__ nbase = reinterpret_cast<const char*>(nrec);
     // PM.cc:405 scan.  Candidates are visited in increasing uj exactly as the reference does (the
     // strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four
-    // at a time so that four independent 16-byte gathers are in flight per lane.
+    // at a time so that four independent 16-byte gathers are in flight per lane.  Fetch addresses
+    // are clamped into the image (32-bit byte offsets from a scalar base); validity is decided
+    // separately from the unclamped values.
     for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
         float4 rs[SCAN_UNROLL];
-        bool vs[SCAN_UNROLL];
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             int uj = u0 + k;
             float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
-            bool v = (uj <= hi) && (yf >= 1.0f && yf < hlim);
-            int vj = v ? (int)yf : 1;
-            int uc = v ? uj : lo;
+            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim2);
+            int uc = min(uj, hi);
+            unsigned off = (unsigned)((int)yc * W + uc) << 4;
             yfs[k] = yf;
-            vs[k] = v;
-            rs[k] = nrec[vj * W + uc];
+            rs[k] = *reinterpret_cast<const float4*>(nbase + off);
         }
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             const int uj = u0 + k;
             if (STATS && uj <= hi) st->candidates++;
-            if (!vs[k]) continue;
             const float yf = yfs[k];
-            const int vj = (int)yf;
             const float4 r = rs[k];
-            if (r.x < prm.lambdaG) continue;  // PM.cc:411
-            float ang_diff = r.y - th_line;   // PM.cc:415-421
+#if SDM_BRANCHFREE_GATES
+            // validity (PM.cc:408 + N3) and the three gates, evaluated branch-free
+            bool pass = (uj <= hi) & (yf >= 1.0f) & (yf < hlim);
+            pass &= !(r.x < prm.lambdaG);    // PM.cc:411
+            float ang_diff = r.y - th_line;  // PM.cc:415-421
+            if (ang_diff >= 360) ang_diff -= 360;
+            if (ang_diff < 0) ang_diff += 360;
+            if (ang_diff > 180) ang_diff = 360 - ang_diff;
+            if (ang_diff > 90) ang_diff = 180 - ang_diff;
+            pass &= !(ang_diff > prm.lambdaL);
+            float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
+            if (th_diff >= 360) th_diff -= 360;
+            if (th_diff < 0) th_diff += 360;
+            if (th_diff > 180) th_diff = 360 - th_diff;
+            pass &= !(th_diff > prm.lambdaTheta);
+            if (!pass) continue;
+#else
+            if (!((uj <= hi) & (yf >= 1.0f) & (yf < hlim))) continue;  // PM.cc:408 + N3
+            if (r.x < prm.lambdaG) continue;                            // PM.cc:411
+            float ang_diff = r.y - th_line;                             // PM.cc:415-421
             if (ang_diff >= 360) ang_diff -= 360;
             if (ang_diff < 0) ang_diff += 360;
             if (ang_diff > 180) ang_diff = 360 - ang_diff;
@@ -307,17 +354,21 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             if (th_diff < 0) th_diff += 360;
             if (th_diff > 180) th_diff = 360 - th_diff;
             if (th_diff > prm.lambdaTheta) continue;
-            if (STATS) st->gate_pass++;
-            float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
-            float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
-            float pe2 = pe * pe, ge2 = ge * ge;
-            float err = (float)((double)pe2 +
-                                div_theta((double)ge2, prm.theta_var, prm.inv_theta, prm.fast_theta_div));  // PM.cc:436
-            if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
-                best_pixel = uj;
-                old_err = err;
-                best_pe = pe;
-                best_ge = ge;
+#endif
+            {
+                if (STATS) st->gate_pass++;
+                const int vj = (int)yf;
+                float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
+                float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
+                float pe2 = pe * pe, ge2 = ge * ge;
+                float err = (float)((double)pe2 + div_theta((double)ge2, prm.theta_var, prm.inv_theta,
+                                                            prm.fast_theta_div));  // PM.cc:436
+                if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
+                    best_pixel = uj;
+                    old_err = err;
+                    best_pe = pe;
+                    best_ge = ge;
+                }
             }
         }
     }
@@ -328,12 +379,11 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float yfp = -(ab * (float)up + cb);
     float yfm = -(ab * (float)um + cb);
     float fyp = floorf(yfp), fym = floorf(yfm);
-    const float hlim2 = (float)(H - 2);
     if (!(fyp >= 0.0f && fyp <= hlim2)) return false;
     if (!(fym >= 0.0f && fym <= hlim2)) return false;
     int y0p = (int)fyp, y0m = (int)fym;
-    float4 rp = nrec[y0p * W + up];
-    float4 rm = nrec[y0m * W + um];
+    float4 rp = *reinterpret_cast<const float4*>(nbase + ((unsigned)(y0p * W + up) << 4));
+    float4 rm = *reinterpret_cast<const float4*>(nbase + ((unsigned)(y0m * W + um) << 4));
     float g = (rec_lerp_im(rp, y0p, yfp) - rec_lerp_im(rm, y0m, yfm)) / 2;      // PM.cc:452
     float q = (rec_lerp_grad(rp, y0p, yfp) - rec_lerp_grad(rm, y0m, yfm)) / 2;  // PM.cc:453
     const double inv_theta = prm.inv_theta;

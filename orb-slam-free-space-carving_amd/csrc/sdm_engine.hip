@@ -280,8 +280,6 @@ int host_alloc(T** p, size_t count)
     return SDM_OK;
 }
 
-size_t search_lds_bytes(int n) { return sizeof(float2) * (size_t)BLOCK * (size_t)std::max(n, 1); }
-
 }  // namespace
 
 extern "C" {
@@ -413,7 +411,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         return bail(fail(SDM_EHIP, "initial memset failed"));
 
     // K1's hypothesis columns can need more than the default 64 KB of dynamic LDS
-    const int max_lds = (int)search_lds_bytes(cfg->max_neighbours);
+    const int max_lds = (int)k1_lds_bytes(cfg->max_neighbours);
     if (hipFuncSetAttribute((const void*)k_search_fuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
             hipSuccess ||
         hipFuncSetAttribute((const void*)k_search_fuse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
@@ -576,9 +574,9 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
                        c->d_ref_slots, n_ref);
     HIP_TRY(hipGetLastError());
     int max_chunks = 0;
-    for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
+    for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + K1_PX - 1) / K1_PX);
     if (max_chunks == 0) return SDM_OK;  // no pixel passes the gradient gate: the maps stay zero
-    const size_t lds = search_lds_bytes(n);
+    const size_t lds = k1_lds_bytes(n);
     const int grid = 8 * ((max_chunks + 7) / 8) * n_ref;
     if (c->stats_on)
         hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,

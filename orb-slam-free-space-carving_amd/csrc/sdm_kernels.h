@@ -247,11 +247,22 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 }
 
 // ---- K1: epipolar search + hypothesis fusion, PM.cc:197-231 --------------------------------------------
-// One thread per ACTIVE pixel of a reference keyframe (256 consecutive list entries per
-// workgroup); the neighbour index j is looped uniformly, so the per-(ref,nbr) constants live in
-// scalar registers and adjacent lanes scan adjacent epipolar segments of the same neighbour.
-// Dynamic LDS: float2 hyp[n][256] -- thread-private hypothesis columns (depth_ho of PM.cc:204).
-// The map was zeroed by k_zero_maps; only fused pixels are written (PM.cc:224-227).
+// Workgroup = 64 consecutive ACTIVE pixels of one reference keyframe x 4 waves.  Wave w searches
+// the neighbours j = w, w+4, w+8, ... for all 64 pixels, so j -- and with it the per-(ref,nbr)
+// constant block -- is wave-uniform (scalar registers) and adjacent lanes scan adjacent epipolar
+// segments of the same neighbour image.  Splitting the neighbours over the waves keeps the LDS
+// footprint at n*64 hypotheses (10 KB at n = 20), which lets 8 waves per SIMD stay resident to
+// hide the gather latency; interleaving j (not blocking it) balances the waves, because the scan
+// length grows with the baseline and neighbours are ordered by covisibility.
+// LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), then the
+// per-(pixel, wave) partial results of the compatibility search.
+constexpr int K1_PX = 64;     // active pixels per workgroup
+constexpr int K1_WAVES = 4;   // neighbour stripes
+__host__ __device__ inline size_t k1_lds_bytes(int n)
+{
+    return sizeof(float2) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1) + (sizeof(unsigned) + sizeof(unsigned long long)) * BLOCK;
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict__ rec, long long plane,
                                                        const RefConst* __restrict__ refs,
@@ -262,6 +273,8 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* hyp = reinterpret_cast<float2*>(smem_raw);
+    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(hyp + (size_t)n * K1_PX);
+    unsigned* pkey = reinterpret_cast<unsigned*>(pmask + BLOCK);
 
     // XCD-aware decode: chunk c of every reference keyframe runs on XCD c % 8
     const int b = blockIdx.x;
@@ -271,9 +284,10 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     const int chunk = (i8 - ref * cpx) * 8 + (b & 7);
     if (ref >= n_ref) return;
     const RefConst rc = refs[ref];
-    const int tid = threadIdx.x;
-    const int t = chunk * BLOCK + tid;
-    if (chunk * BLOCK >= rc.act_count) return;
+    if (chunk * K1_PX >= rc.act_count) return;
+    const int tid = threadIdx.x, p = tid & (K1_PX - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = chunk * K1_PX + p;
     const bool on = t < rc.act_count;
     const float4* __restrict__ rrec = rec + (long long)rc.slot * plane;
 
@@ -292,30 +306,76 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     }
     SearchStats st = {0, 0, 0};
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
-    int nh = 0;
-    for (int j = 0; j < n; j++) {
+    for (int j = w; j < n; j += K1_WAVES) {
         const PairConst* __restrict__ pc = pcs + j;
         const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
+        float2 h = make_float2(__builtin_nanf(""), 0.f);
         if (on) {
             float rho, sigma, bu, bv;
             bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0, xp1,
                                              rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
-            if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
-                hyp[nh * BLOCK + tid] = make_float2(rho, sigma);
-                nh++;
+            if (ok && (1.0f / rho) > 0.0f) h = make_float2(rho, sigma);  // PM.cc:216
+        }
+        hyp[j * K1_PX + p] = h;
+    }
+    __syncthreads();
+
+    // InverseDepthHypothesisFusion, PM.cc:598-626: wave w evaluates the compatibility rows
+    // a = w, w+4, ...; the winner is the largest set, ties to the smallest a (PM.cc:616 strict '>').
+    unsigned long long vm = 0;
+    for (int bb = 0; bb < n; bb++) {
+        float r0 = hyp[bb * K1_PX + p].x;
+        if (r0 == r0) vm |= 1ull << bb;
+    }
+    const int nh = __popcll(vm);
+    unsigned bestkey = 0;
+    unsigned long long bestmask = 0;
+    if (nh > prm.lambdaN) {  // PM.cc:221
+        for (int a = w; a < n; a += K1_WAVES) {
+            if (!((vm >> a) & 1ull)) continue;
+            const float2 ha = hyp[a * K1_PX + p];
+            const float ra = safe_rcp_sq(ha.y);
+            unsigned long long m = 0;
+            for (int bb = 0; bb < n; bb++) {
+                if (!((vm >> bb) & 1ull)) continue;
+                const float2 hb = hyp[bb * K1_PX + p];
+                if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, safe_rcp_sq(hb.y))) m |= 1ull << bb;
+            }
+            const unsigned key = ((unsigned)__popcll(m) << 6) | (unsigned)(63 - a);
+            if (key > bestkey) {
+                bestkey = key;
+                bestmask = m;
             }
         }
     }
+    pkey[tid] = bestkey;
+    pmask[tid] = bestmask;
+    __syncthreads();
+
     unsigned long long n_fused = 0;
-    if (on && nh > prm.lambdaN) {  // PM.cc:221
-        float rho, sigma;
-        if (fuse_column(hyp + tid, BLOCK, nh, prm.lambdaN, rho, sigma)) {  // PM.cc:223-227
-            pool[(long long)rc.slot * plane + y * W + x] = make_float2(rho, sigma);
+    if (w == 0 && on && nh > prm.lambdaN) {
+#pragma unroll
+        for (int q = 1; q < K1_WAVES; q++) {
+            const unsigned k2 = pkey[q * K1_PX + p];
+            if (k2 > bestkey) {
+                bestkey = k2;
+                bestmask = pmask[q * K1_PX + p];
+            }
+        }
+        if ((int)(bestkey >> 6) >= prm.lambdaN) {  // PM.cc:623
+            float pjsj = 0.f, rsj = 0.f;          // GetFusion overload B, PM.cc:947-970
+            for (int bb = 0; bb < n; bb++) {
+                if (!((bestmask >> bb) & 1ull)) continue;
+                const float2 hb = hyp[bb * K1_PX + p];
+                fusion_accum(hb.x, hb.y, pjsj, rsj);
+            }
+            pool[(long long)rc.slot * plane + y * W + x] = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
             n_fused = 1;
         }
     }
     if (STATS) {
-        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass, (unsigned long long)nh, n_fused};
+        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass,
+                                   (w == 0 && on) ? (unsigned long long)nh : 0ull, n_fused};
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             unsigned long long s = v[k];

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects rocprofv3 PMC counters for one bench configuration, one counter group per pass
+# (gpurun refuses --pmc combined with trace domains; FETCH_SIZE and WRITE_SIZE cannot share a pass).
+# usage (on the GPU box, from the repo root): tools/pmc.sh <tag> [bench args...]
+set -u
+TAG=$1; shift
+OUT=gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+i=0
+while IFS= read -r group; do
+  [ -z "$group" ] && continue
+  i=$((i+1))
+  rocprofv3 --pmc $group --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --cpu-kfs 0 --no-stats "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed"
+done <<'GROUPS'
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+FETCH_SIZE
+WRITE_SIZE
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_READ_sum
+SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
+SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAVES GRBM_GUI_ACTIVE
+GROUPS
+python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
