@@ -63,6 +63,8 @@ struct sdm_ctx {
     int* d_act_count = nullptr;    // [max_keyframes]
     std::vector<int> h_act_count;  // host mirror
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
+    std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
+                                       // came from elsewhere, e.g. sdm_upload_depth): K4 may use the list
 
     // staging for one keyframe
     uint8_t* d_im = nullptr;
@@ -352,6 +354,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->has_chk.assign(K, 0);
     c->h_act_count.assign(K, 0);
     c->act_lambdaG.assign(K, std::nanf(""));
+    c->recon_lambdaG.assign(K, std::nanf(""));
 
     int rc = SDM_OK;
     auto bail = [&](int code) {
@@ -597,7 +600,10 @@ int sdm_search_fuse(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;
-    for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;
+    for (int r = 0; r < n_ref; r++) {
+        c->has_depth[ref_slots[r]] = 1;
+        c->recon_lambdaG[ref_slots[r]] = c->dprm.lambdaG;
+    }
     return tables_staged(c);
 }
 
@@ -690,7 +696,10 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
     if ((rc = run_intra(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
-    for (int r = 0; r < n_ref; r++) c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244
+    for (int r = 0; r < n_ref; r++) {
+        c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244
+        c->recon_lambdaG[ref_slots[r]] = c->dprm.lambdaG;
+    }
     return tables_staged(c);
 }
 
@@ -703,9 +712,27 @@ int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
     if (rc) return rc;
     {
         StageTimer tm(c, SDM_STAGE_INTER);
-        hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
-                           c->d_refs, c->d_pairs, n_ref, n, c->geom, c->dprm.lambdaN, c->chk);
-        HIP_TRY(hipGetLastError());
+        bool from_recon = true;  // every reference map produced by SemiDenseRecon under the current lambdaG?
+        int max_chunks = 0;
+        for (int r = 0; r < n_ref; r++) {
+            from_recon = from_recon && (c->recon_lambdaG[ref_slots[r]] == c->dprm.lambdaG);
+            max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
+        }
+        if (from_recon) {
+            hipLaunchKernelGGL(k_rho_copy, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->chk,
+                               c->P, c->d_ref_slots, n_ref);
+            HIP_TRY(hipGetLastError());
+            if (max_chunks > 0) {
+                hipLaunchKernelGGL(k_inter_check_list, dim3(8 * ((max_chunks + 7) / 8) * n_ref), dim3(BLOCK), 0,
+                                   c->stream, c->pool, c->P, c->d_refs, c->d_pairs, n_ref, n, c->W, c->H, max_chunks,
+                                   c->dprm.lambdaN, c->d_act, c->chk);
+                HIP_TRY(hipGetLastError());
+            }
+        } else {
+            hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
+                               c->P, c->d_refs, c->d_pairs, n_ref, n, c->geom, c->dprm.lambdaN, c->chk);
+            HIP_TRY(hipGetLastError());
+        }
         if (commit) {
             hipLaunchKernelGGL(k_commit, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->chk, c->pool,
                                c->P, c->d_ref_slots, n_ref);
@@ -758,6 +785,7 @@ int sdm_upload_depth(sdm_ctx* c, int slot, const float* rho, const float* sigma)
     if (!rho || !sigma) return fail(SDM_EINVAL, "null map");
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->has_depth[slot] = 1;
+    c->recon_lambdaG[slot] = std::nanf("");  // arbitrary map: support is no longer tied to the active list
     return upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma);
 }
 

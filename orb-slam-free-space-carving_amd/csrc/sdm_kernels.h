@@ -535,8 +535,69 @@ __global__ __launch_bounds__(BLOCK) void k_intra_grow(const float2* __restrict__
 }
 
 // ---- K4: InterKeyFrameDepthChecking, PM.cc:628-799 ------------------------------------------------------
-// Reads the neighbours' {rho,sigma} from the depth pool (4 taps, PM.cc:705-752), writes the
-// reference keyframe's checked rho to chk[slot].
+// The "test < 3.84" decision of PM.cc:709-710 (a double division per tap) is pre-filtered with a
+// float reciprocal exactly like ChiTest (sdm_device.h): only results inside the band
+// 3.84*(1 +- 2^-14), or unsafe sigmas, take the exact double path.
+__device__ __forceinline__ bool tap_compatible(float depthj, float d, float sg)
+{
+    float dd = depthj - d;
+    float approx = (dd * dd) * safe_rcp_sq(sg);
+    if (approx < 3.8397f) return true;
+    if (approx > 3.8403f) return false;
+    float test = (float)(((double)dd * (double)dd) / ((double)sg * (double)sg));  // PM.cc:709
+    return (double)test < 3.84;
+}
+
+// One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764).
+__device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool, long long plane,
+                                                   const RefConst& rc, const PairConst* __restrict__ pcs, int n,
+                                                   int W, int H, int x, int y, float depthp, int lambdaN)
+{
+    const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
+    const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
+    const float dp = 1 / depthp;                                                        // PM.cc:769
+    int kf_count = 0;
+    float sum_Jr = 0.f, sum_JJ = 0.f;
+    for (int j = 0; j < n; j++) {
+        const PairConst* __restrict__ pc = pcs + j;
+        const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
+        float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
+        float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
+        float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+        float t2 = rzxp / depthp + pc->t[2];
+        float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
+        float v = pc->nfy * t1 + pc->ncy * t2;
+        float xj = u / t2, yj = v / t2;  // PM.cc:680
+        float denom2 = depthp * pc->t[2];
+        float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+        if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) continue;  // PM.cc:695
+        int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
+        // four taps fetched together; order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+        float2 h[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = nb[(y0 + (k & 1)) * W + x0 + (k >> 1)];
+        int nj = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((double)h[k].x > 0.000001 && tap_compatible(depthj, h[k].x, h[k].y)) {
+                nj++;
+                float djn = 1 / h[k].x;  // PM.cc:777-783
+                float d2sigma = djn * djn * h[k].y;
+                float J = -rzxp / d2sigma;
+                float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;
+                sum_Jr = sum_Jr + J * r0;
+                sum_JJ = sum_JJ + J * J;
+            }
+        }
+        if (nj >= 1) kf_count++;  // PM.cc:755
+    }
+    if (kf_count < lambdaN) return 0.0f;   // PM.cc:764
+    float dpDelta = (-sum_Jr) / sum_JJ;    // PM.cc:788-791
+    return 1 / (dp + dpDelta);             // PM.cc:793
+}
+
+// Generic form: any depth map (e.g. uploaded by the caller).  64x16 tiles, in-tile compaction of
+// the pixels that are not skipped by PM.cc:662, results staged in LDS, full-tile write-back.
 __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict__ pool, long long plane,
                                                        const RefConst* __restrict__ refs,
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
@@ -563,61 +624,12 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict_
     const int nAct = block_compact(f, act, wsum);
     __syncthreads();
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
-    const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
     for (int base = 0; base < nAct; base += BLOCK) {
         const int t = base + tid;
-        const bool on = t < nAct;
-        const int L = on ? act[t] : 0;
+        if (t >= nAct) continue;
+        const int L = act[t];
         const int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
-        const float depthp = outv[L];
-        const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
-        const float dp = 1 / depthp;                                                        // PM.cc:769
-        int kf_count = 0;
-        float sum_Jr = 0.f, sum_JJ = 0.f;
-        for (int j = 0; j < n; j++) {
-            const PairConst* __restrict__ pc = pcs + j;
-            if (!on) continue;
-            const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
-            float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
-            float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
-            float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-            float t2 = rzxp / depthp + pc->t[2];
-            float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
-            float v = pc->nfy * t1 + pc->ncy * t2;
-            float xj = u / t2, yj = v / t2;  // PM.cc:680
-            float denom2 = depthp * pc->t[2];
-            float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
-            if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) continue;  // PM.cc:695
-            int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
-            int nj = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {  // order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
-                int tx = x0 + (k >> 1), ty = y0 + (k & 1);
-                float2 h = nb[ty * W + tx];
-                if ((double)h.x > 0.000001) {
-                    float dd = depthj - h.x;
-                    float test = (float)(((double)dd * (double)dd) / ((double)h.y * (double)h.y));  // PM.cc:709
-                    if ((double)test < 3.84) {
-                        nj++;
-                        float djn = 1 / h.x;  // PM.cc:777-783
-                        float d2sigma = djn * djn * h.y;
-                        float J = -rzxp / d2sigma;
-                        float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;
-                        sum_Jr = sum_Jr + J * r0;
-                        sum_JJ = sum_JJ + J * J;
-                    }
-                }
-            }
-            if (nj >= 1) kf_count++;  // PM.cc:755
-        }
-        if (on) {
-            if (kf_count < lambdaN) {
-                outv[L] = 0.0f;  // PM.cc:764
-            } else {
-                float dpDelta = (-sum_Jr) / sum_JJ;  // PM.cc:788-791
-                outv[L] = 1 / (dp + dpDelta);       // PM.cc:793
-            }
-        }
+        outv[L] = inter_check_pixel(pool, plane, rc, pcs, n, W, H, x, y, outv[L], lambdaN);
     }
     __syncthreads();
     float* __restrict__ out = chk + (long long)rc.slot * plane;
@@ -627,6 +639,44 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict_
         int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
         if (x < W && y < H) out[y * W + x] = outv[L];
     }
+}
+
+// Pipeline form: the depth map was produced by SemiDenseRecon, so every supported pixel is in the
+// keyframe's active-pixel list (K1 writes only listed pixels, K2 only removes support, K3 grows
+// only pixels with GradImg >= lambdaG).  One thread per list entry, no LDS; k_rho_copy has already
+// copied rho into the checked plane.
+__global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __restrict__ pool, long long plane,
+                                                            const RefConst* __restrict__ refs,
+                                                            const PairConst* __restrict__ pairs, int n_ref, int n,
+                                                            int W, int H, int max_chunks, int lambdaN,
+                                                            const unsigned* __restrict__ act, float* __restrict__ chk)
+{
+    const int b = blockIdx.x;
+    const int cpx = (max_chunks + 7) >> 3;
+    const int i8 = b >> 3;
+    const int ref = i8 / cpx;
+    const int chunk = (i8 - ref * cpx) * 8 + (b & 7);
+    if (ref >= n_ref) return;
+    const RefConst rc = refs[ref];
+    const int t = chunk * BLOCK + threadIdx.x;
+    if (t >= rc.act_count) return;
+    const unsigned xy = act[(long long)rc.slot * plane + t];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const long long o = (long long)rc.slot * plane + y * W + x;
+    const float depthp = pool[o].x;
+    if ((double)depthp < 0.000001) return;  // PM.cc:662 (the checked plane already holds rho)
+    chk[o] = inter_check_pixel(pool, plane, rc, pairs + (long long)ref * n, n, W, H, x, y, depthp, lambdaN);
+}
+
+// rho plane of the depth map -> checked plane
+__global__ __launch_bounds__(BLOCK) void k_rho_copy(const float2* __restrict__ pool, float* __restrict__ chk,
+                                                    long long plane, const int* __restrict__ slots, int n_ref)
+{
+    long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= plane * n_ref) return;
+    int r = (int)(idx / plane);
+    long long o = (long long)slots[r] * plane + (idx - (long long)r * plane);
+    chk[o] = pool[o].x;
 }
 
 // chk -> depth map rho (the reference's in-place write, PM.cc:764/793)
