@@ -256,7 +256,7 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
 // nrec: the neighbour keyframe's record plane.  Returns true iff a hypothesis was produced
-// (dh.supported).  Normative deviations N3-N5 as in oracle/pm_oracle.c / DESIGN.md §3.
+// (dh.supported).  Normative choices N3-N5 for the reference's undefined behaviour: DESIGN.md §3.
 template <bool STATS>
 __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
                                                 const PairConst* __restrict__ pc, float fx,

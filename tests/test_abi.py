@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sdm_c.h declares; host-side helpers
+of the class surface; no compute calls without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sdm_c.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(pkg):
+    lib = pkg.load_library()
+    names = declared_symbols()
+    assert len(names) >= 35
+    raw = ctypes.CDLL(pkg.lib_path())
+    for n in names:
+        assert hasattr(raw, n), "libsdm_hip.so does not export %s" % n
+    bound = {s[0] for s in pkg.binding.SYMBOLS} if hasattr(pkg, "binding") else None
+    from importlib import import_module
+    import sys
+    binding = sys.modules[pkg.__name__ + ".binding"]
+    assert sorted(s[0] for s in binding.SYMBOLS) == names, "ctypes mirror out of sync with sdm_c.h"
+
+
+def test_struct_layouts(pkg):
+    import sys
+    b = sys.modules[pkg.__name__ + ".binding"]
+    # sdm_params {float,float,float,int,double} and sdm_config as laid out by the C compiler
+    assert ctypes.sizeof(b.Params) == 24
+    assert ctypes.sizeof(b.Config) == 48
+    assert ctypes.sizeof(b.Stats) == 40
+    lib = pkg.load_library()
+    p = b.Params()
+    lib.sdm_default_params(ctypes.byref(p))
+    # PM.h:38-49 defaults
+    assert (p.lambdaG, p.lambdaL, p.lambdaTheta, p.lambdaN, p.theta_var) == (8.0, 80.0, 45.0, 3, 0.23)
+    c = b.Config()
+    lib.sdm_default_config(ctypes.byref(c))
+    assert c.max_neighbours == 7  # covisN, PM.h:38
+    assert lib.sdm_depth_pool_bytes(640, 480, 3) == 8 * 640 * 480 * 3
+
+
+def test_no_cpu_fallback(pkg):
+    lib = pkg.load_library()
+    if lib.sdm_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pkg.SdmError) as e:
+        pkg.Engine(64, 48, 2)
+    assert e.value.code == 3  # SDM_ENODEV
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_host_helpers_match_oracle(pkg, oracle):
+    import sys
+    b = sys.modules[pkg.__name__ + ".binding"]
+    rng = np.random.default_rng(0)
+    for n in [1, 5, 100, 1000]:
+        d = (1 + 0.3 * rng.standard_normal(n)).astype(np.float32)
+        got = b.stereo_search_constraints(d)
+        ref = oracle.stereo_search_constraints(d)
+        assert np.float32(got[0]).view(np.uint32) == np.float32(ref[0]).view(np.uint32)
+        assert np.float32(got[1]).view(np.uint32) == np.float32(ref[1]).view(np.uint32)
+    for _ in range(20):
+        n1, n2 = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        mp1 = rng.integers(-1, 30, n1)
+        mp2 = rng.integers(-1, 30, n2)
+        a1 = rng.uniform(-20, 360, n1).astype(np.float32)
+        a2 = rng.uniform(-20, 360, n2).astype(np.float32)
+        assert b.median_rot_in_plane(mp1, a1, mp2, a2) == oracle.median_rot_in_plane(mp1, a1, mp2, a2)
+
+
+def test_product_does_not_touch_oracle():
+    """the product path must not import, link or call anything under oracle/"""
+    bad = []
+    for base in ("orb-slam-free-space-carving_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cc", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"pm_oracle|pmo_|oracle/", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,168 @@
+"""GPU: BASELINE.json's full sizes.  The oracle checks a sample of keyframes bit for bit (it needs
+~0.3 s per 640x480 keyframe at N = 20); every keyframe is covered by size-independent properties:
+batch invariance, determinism, inset/gate structure of the support mask, monotone support through
+the inter-keyframe check, absolute accuracy against the analytic ground truth of the synthetic
+plane (tolerances stated at each assert), and the back-projection round trip."""
+import numpy as np
+import pytest
+import torch
+
+from common import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuSequence:
+    """images rendered on the GPU, gradient pre-pass on the device (inputs of the bench)"""
+
+    def __init__(self, pkg, cam, n_kf, n, seed, disparity_px=2.6):
+        self.pkg, self.n_kf, self.n = pkg, n_kf, n
+        self.scene = pkg.synth.Scene(cam, seed, disparity_px=disparity_px)
+        self.W, self.H = cam["W"], cam["H"]
+        self.eng = pkg.Engine(self.W, self.H, n_kf, max_neighbours=n)
+        self.K = self.scene.K()
+        self.im, self.gt = {}, {}
+        for k in range(n_kf):
+            im, gt = self.scene.render(k, device="cuda")
+            torch.cuda.synchronize()
+            self.eng.upload_image_device(k, im.data_ptr(), self.K, self.scene.Tcw(k))
+            self.im[k] = im.cpu().numpy()
+            self.gt[k] = gt.cpu().numpy()
+        self.min_d, self.max_d = self.scene.depth_prior()
+        self.refs = list(range(n_kf))
+        self.nbrs = [self.scene.neighbours(k, n_kf, n) for k in self.refs]
+
+    def oracle_kf(self, oracle, k):
+        g, t, s = oracle.gradient_prepass(self.im[k])
+        return oracle.keyframe(self.im[k], g, t, s, self.K, self.scene.Tcw(k))
+
+
+def check_properties(seq, maps, chk, xyz, acc_tol):
+    eng = seq.eng
+    W, H = seq.W, seq.H
+    sup_total = 0
+    for k in seq.refs:
+        r, s = maps[k]
+        c = chk[k]
+        _, grad, _, _ = eng.download_inputs(k) if k % 16 == 0 else (None, None, None, None)
+        sup = r > 1e-6
+        # inset: nothing in the 2-px border (PM.cc:198-199)
+        assert not r[:2].any() and not r[-2:].any() and not r[:, :2].any() and not r[:, -2:].any()
+        if grad is not None:
+            assert not (sup & (grad < 8)).any(), "support only where GradImg >= lambdaG (PM.cc:201,562)"
+        # the inter-keyframe check only removes or refines support (PM.cc:762-794)
+        assert not ((c > 1e-6) & ~sup).any()
+        # absolute accuracy vs the analytic plane: median |rho - rho_gt| (stated tolerance acc_tol)
+        m = c > 1e-6
+        if m.sum() > 1000:
+            err = np.abs(c[m] - seq.gt[k][m])
+            assert np.median(err) < acc_tol, (k, float(np.median(err)))
+        sup_total += int(m.sum())
+        # back-projection round trip, |reprojection - pixel| < 2e-3 px, |1/Z - rho| < 1e-5*rho
+        if k % 16 == 0:
+            P = xyz[k].reshape(H, W, 3).astype(np.float64)
+            T = seq.scene.Tcw(k).astype(np.float64)
+            Xc = P @ T[:, :3].T + T[:, 3]
+            ys, xs = np.nonzero(m)
+            fx, fy, cx, cy = [float(v) for v in seq.K]
+            assert np.abs(fx * Xc[ys, xs, 0] / Xc[ys, xs, 2] + cx - xs).max() < 2e-3
+            assert np.abs(fy * Xc[ys, xs, 1] / Xc[ys, xs, 2] + cy - ys).max() < 2e-3
+            assert (np.abs(1 / Xc[ys, xs, 2] - c[ys, xs]) < 1e-5 * c[ys, xs] + 1e-7).all()
+            assert not P[~m].any()
+    return sup_total
+
+
+def run_all(seq):
+    eng = seq.eng
+    eng.recon(seq.refs, seq.nbrs, seq.min_d, seq.max_d)
+    eng.inter_check(seq.refs, seq.nbrs)
+    eng.pointset(seq.refs, source=1)
+    maps = {k: eng.download_depth(k) for k in seq.refs}
+    chk = {k: eng.download_checked(k) for k in seq.refs}
+    return maps, chk
+
+
+def test_config2_640x480_64kf_n20(pkg, oracle, gpu_ok):
+    """BASELINE.json configs[1]: the bench workload"""
+    seq = GpuSequence(pkg, pkg.synth.TUM1, 64, 20, 0x5EED0002)
+    maps, chk = run_all(seq)
+    xyz = {k: seq.eng.download_pointset(k) for k in seq.refs if k % 16 == 0}
+    sup = check_properties(seq, maps, chk, xyz, acc_tol=2e-3)
+    assert sup > 0.10 * 64 * 640 * 480, "semi-dense coverage"
+    # oracle sample: first, middle and last keyframe, bit-exact
+    for k in (0, 31, 63):
+        kf = {j: seq.oracle_kf(oracle, j) for j in [k] + seq.nbrs[k]}
+        r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in seq.nbrs[k]], None, seq.min_d, seq.max_d)
+        assert_bit_equal(maps[k][0], r, "rho kf %d" % k)
+        assert_bit_equal(maps[k][1], s, "sigma kf %d" % k)
+        c = oracle.inter_check(kf[k], r, [kf[j] for j in seq.nbrs[k]], [maps[j][0] for j in seq.nbrs[k]],
+                               [maps[j][1] for j in seq.nbrs[k]])
+        assert_bit_equal(chk[k], c, "checked rho kf %d" % k)
+    # determinism + batch invariance: two half-batches reproduce the single batch bit for bit
+    eng = seq.eng
+    eng.recon(seq.refs[:32], seq.nbrs[:32], seq.min_d, seq.max_d)
+    eng.recon(seq.refs[32:], seq.nbrs[32:], seq.min_d, seq.max_d)
+    for k in (0, 17, 31, 32, 50, 63):
+        r, s = eng.download_depth(k)
+        assert_bit_equal(r, maps[k][0])
+        assert_bit_equal(s, maps[k][1])
+    eng.close()
+
+
+def test_config3_1280x720_n7(pkg, oracle, gpu_ok):
+    """BASELINE.json configs[2] geometry (HD720 intrinsics, N = 7); 16 keyframes of the 256"""
+    seq = GpuSequence(pkg, pkg.synth.HD720, 16, 7, 0x5EED0003)
+    maps, chk = run_all(seq)
+    xyz = {k: seq.eng.download_pointset(k) for k in seq.refs if k % 16 == 0}
+    check_properties(seq, maps, chk, xyz, acc_tol=2e-3)
+    k = 8
+    kf = {j: seq.oracle_kf(oracle, j) for j in [k] + seq.nbrs[k]}
+    r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in seq.nbrs[k]], None, seq.min_d, seq.max_d)
+    assert_bit_equal(maps[k][0], r)
+    assert_bit_equal(maps[k][1], s)
+    seq.eng.close()
+
+
+def test_config4_1920x1080_n7(pkg, oracle, gpu_ok):
+    """BASELINE.json configs[3] geometry (1080p, N = 7); 8 keyframes of one GPU's shard"""
+    seq = GpuSequence(pkg, pkg.synth.HD1080, 8, 7, 0x5EED0004)
+    maps, chk = run_all(seq)
+    xyz = {k: seq.eng.download_pointset(k) for k in seq.refs if k % 16 == 0}
+    check_properties(seq, maps, chk, xyz, acc_tol=2e-3)
+    k = 4
+    kf = {j: seq.oracle_kf(oracle, j) for j in [k] + seq.nbrs[k]}
+    r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in seq.nbrs[k]], None, seq.min_d, seq.max_d)
+    assert_bit_equal(maps[k][0], r)
+    assert_bit_equal(maps[k][1], s)
+    c = oracle.inter_check(kf[k], r, [kf[j] for j in seq.nbrs[k]], [maps[j][0] for j in seq.nbrs[k]],
+                           [maps[j][1] for j in seq.nbrs[k]])
+    assert_bit_equal(chk[k], c)
+    seq.eng.close()
+
+
+def test_external_pool_and_stream(pkg, oracle, gpu_ok):
+    """the bench's plumbing: depth pool owned by torch (what RCCL all-gathers in place) and the
+    engine running on a torch stream; the pool tensor IS the depth map"""
+    cam = pkg.synth.scaled_intrinsics(pkg.synth.TUM1, 160, 120)
+    scene = pkg.synth.Scene(cam, 0x5EED0A02)
+    n_kf, n = 8, 7
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        pool = torch.zeros((n_kf, 120, 160, 2), dtype=torch.float32, device="cuda")
+        eng = pkg.Engine(160, 120, n_kf, max_neighbours=n, ext_depth_pool=pool.data_ptr(), stream=stream.cuda_stream)
+        assert eng.depth_pool_ptr() == pool.data_ptr()
+        for k in range(n_kf):
+            im, _ = scene.render(k, device="cuda")
+            torch.cuda.synchronize()
+            eng.upload_image_device(k, im.data_ptr(), scene.K(), scene.Tcw(k))
+        refs = list(range(n_kf))
+        nbrs = [scene.neighbours(k, n_kf, n) for k in refs]
+        mn, mx = scene.depth_prior()
+        eng.recon(refs, nbrs, mn, mx)
+        stream.synchronize()
+        for k in (0, 5):
+            r, s = eng.download_depth(k)
+            assert_bit_equal(pool[k, :, :, 0].cpu().numpy(), r)
+            assert_bit_equal(pool[k, :, :, 1].cpu().numpy(), s)
+            assert (r > 1e-6).sum() > 500
+        eng.close()

@@ -1,0 +1,109 @@
+"""CPU: synthetic-scene generator, keyframe sharding plan, and the N>1 exchange step on gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_neighbour_order(pkg):
+    nb = pkg.synth.Scene.neighbours
+    assert nb(5, 20, 4) == [6, 4, 7, 3]          # |dk| ascending, +dk before -dk
+    assert nb(0, 20, 4) == [1, 2, 3, 4]          # clipped at the sequence start
+    assert nb(19, 20, 3) == [18, 17, 16]
+    assert nb(1, 20, 4) == [2, 0, 3, 4]
+    with pytest.raises(ValueError):
+        nb(0, 4, 4)
+
+
+def test_scene_determinism_and_geometry(pkg):
+    synth = pkg.synth
+    cam = synth.scaled_intrinsics(synth.TUM1, 80, 60)
+    a = synth.Scene(cam, 123)
+    b = synth.Scene(cam, 123)
+    ia, ga = a.render(3)
+    ib, gb = b.render(3)
+    assert torch.equal(ia, ib) and torch.equal(ga, gb)
+    assert not torch.equal(ia, synth.Scene(cam, 124).render(3)[0])
+    # ground-truth inverse depth is ~1 (Z0 = 1) and the pose is a rigid transform
+    assert 0.8 < float(ga.mean()) < 1.2
+    T = a.Tcw(3)
+    R = T[:, :3].astype(np.float64)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)
+    # adjacent keyframes are disparity_px apart at Z0
+    C3, C4 = a.pose(3)[1], a.pose(4)[1]
+    assert abs((C4[0] - C3[0]) * cam["fx"] - 2.6) < 1e-9
+    mn, mx = a.depth_prior()
+    assert abs(mn - 1.25) < 1e-6 and abs(mx - 1 / 1.2) < 1e-6  # PM.cc:381-382 with mu = 1, s = 0.1
+
+
+def test_shard_plan_covers_everything(pkg):
+    shard, nb = pkg.shard, pkg.synth.Scene.neighbours
+    n_total, world, n = 32, 4, 6
+    seen = []
+    for r in range(world):
+        pl = shard.plan(n_total, world, r, n, nb)
+        assert pl["count"] == 8 and pl["first"] == 8 * r
+        seen += pl["own"]
+        for k, row in zip(pl["own"], pl["nbrs"]):
+            assert row == nb(k, n_total, n)
+            assert set(row) <= set(pl["inputs"])       # input halo is local
+        assert set(pl["own"]) <= set(pl["inputs"])
+        assert len(pl["inputs"]) <= 8 + n              # halo is at most n/2 each side (+ clipping)
+    assert sorted(seen) == list(range(n_total))
+    with pytest.raises(ValueError):
+        shard.plan(30, 4, 0, n, nb)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, H, W, out):
+    sys.path.insert(0, ROOT)
+    import sdm_pkg
+    pkg = sdm_pkg.load()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pl = pkg.shard.plan(n_total, world, rank, 4, pkg.synth.Scene.neighbours)
+    pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32)
+    # stand-in for K1-K3: this rank fills only its own block with a recognisable pattern
+    for k in pl["own"]:
+        pool[k, :, :, 0] = k + 0.25
+        pool[k, :, :, 1] = -(k + 0.5)
+    pkg.shard.allgather_depth(pool, pl["first"], pl["count"])
+    ok = True
+    for k in range(n_total):
+        ok = ok and bool((pool[k, :, :, 0] == k + 0.25).all()) and bool((pool[k, :, :, 1] == -(k + 0.5)).all())
+    # every neighbour a rank's K4 will read is now present
+    for row in pl["nbrs"]:
+        for j in row:
+            ok = ok and float(pool[j, 0, 0, 0]) == j + 0.25
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_allgather_exchange_gloo_world2(pkg):
+    """the one exchange step of the path (all-gather of per-keyframe {rho,sigma} maps between K3 and
+    K4), world_size 2 on the gloo backend"""
+    world, n_total = 2, 12
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, 6, 8, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(out) == {0: True, 1: True}
