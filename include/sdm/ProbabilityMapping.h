@@ -1,0 +1,146 @@
+/*
+ * sdm/ProbabilityMapping.h -- the reference's ProbabilityMapping class surface over the MI355X
+ * engine (C ABI: include/sdm_c.h).
+ *
+ * Mirrors /root/reference/include/Modeler/ProbabilityMapping.h:61-105 ("PM.h"): same class name,
+ * same public method names, same argument order and meaning, same void returns (errors are printed
+ * to std::cerr, the convention of the surrounding Modeler code,
+ * src/Modeler/SFMTranscriptInterface_ORBSLAM.cpp:213-215).  The only substitutions are the types
+ * the container cannot provide (no OpenCV, no ORB_SLAM2 headers):
+ *
+ *     cv::Mat (CV_32FC1 / CV_8UC1)   ->  sdm::Mat<float> / sdm::Mat<uint8_t>  (rows, cols, at(y,x), clone())
+ *     ORB_SLAM2::KeyFrame            ->  sdm::KeyFrame  (exactly the members PM.cc touches)
+ *     ORB_SLAM2::Map                 ->  sdm::Map       (GetAllKeyFrames(), include/Map.h:58)
+ *
+ * INTEGRATION.md shows the adapter a maintainer of the fork writes to fill sdm::KeyFrame from the
+ * real cv::Mat / ORB_SLAM2::KeyFrame.  All arithmetic runs on the GPU; this header and
+ * host/ProbabilityMapping.cc only move data and keep the per-keyframe flags.
+ */
+#ifndef SDM_PROBABILITY_MAPPING_H
+#define SDM_PROBABILITY_MAPPING_H
+
+#include <cstdint>
+#include <map>
+#include <vector>
+
+/* PM.h:38-49.  covisN is a runtime value here (sdm::Options::covisN, default 7). */
+#define SDM_COVISN_DEFAULT 7
+
+struct sdm_ctx;
+
+namespace sdm {
+
+/* Minimal dense 2-D array with cv::Mat-like value semantics: copies share nothing. */
+template <typename T>
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    std::vector<T> data;
+    Mat() {}
+    Mat(int r, int c, T v = T()) : rows(r), cols(c), data((size_t)r * (size_t)c, v) {}
+    T& at(int y, int x) { return data[(size_t)y * cols + x]; }
+    const T& at(int y, int x) const { return data[(size_t)y * cols + x]; }
+    Mat clone() const { return *this; }
+    bool empty() const { return data.empty(); }
+    T* ptr() { return data.data(); }
+    const T* ptr() const { return data.data(); }
+};
+
+/* The KeyFrame contract PM.cc assumes (use sites in PM.cc given per member). */
+class KeyFrame {
+public:
+    long unsigned int mnId = 0;
+    Mat<uint8_t> im_;             /* PM.cc:114,202,433   CV_8UC1 gray                      */
+    Mat<float> GradImg;           /* PM.cc:201,411,434   gradient magnitude                */
+    Mat<float> GradTheta;         /* PM.cc:214,415,427   gradient direction, deg [0,360)   */
+    float I_stddev = 0.f;         /* PM.cc:457                                              */
+    Mat<float> depth_map_;        /* PM.cc:225,237,345   inverse depth, zero-initialised   */
+    Mat<float> depth_sigma_;      /* PM.cc:226,237                                          */
+    Mat<float> SemiDensePointSets_; /* PM.cc:117-119,346-363  H x 3W                        */
+    bool semidense_flag_ = false;   /* PM.cc:141,244 */
+    bool interKF_depth_flag_ = false; /* PM.cc:265,306 */
+    bool poseChanged = false;         /* PM.cc:329-331 */
+    float fx = 0, fy = 0, cx = 0, cy = 0; /* include/KeyFrame.h:162 */
+    float Tcw[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; /* [R|t] row-major, src/KeyFrame.cc:70-121 */
+    bool bad = false, mapped = true;
+    std::vector<KeyFrame*> covisible;  /* GetVectorCovisibleKeyFrames(): descending weight, KeyFrame.cc:168-172 */
+    std::vector<float> point_depths;   /* GetAllPointDepths(), PM.cc:371 */
+    std::vector<int> map_point_ids;    /* GetMapPointMatches(): id per keypoint, -1 = none, PM.cc:468-469 */
+    std::vector<float> keypoint_angles; /* GetKeyPointsUn()[i].angle, deg, <0 = none, PM.cc:475-476 */
+
+    bool isBad() const { return bad; }
+    bool Mapped() const { return mapped; }
+    const Mat<uint8_t>& GetImage() const { return im_; }
+    const std::vector<KeyFrame*>& GetVectorCovisibleKeyFrames() const { return covisible; }
+    const std::vector<float>& GetAllPointDepths() const { return point_depths; }
+    /* fills GradImg / GradTheta / I_stddev / zeroed maps from im_ ON THE GPU (the pre-processing the
+     * reference leaves to KeyFrame); called lazily by ProbabilityMapping when GradImg is empty. */
+};
+
+class Map {
+public:
+    std::vector<KeyFrame*> keyframes;
+    std::vector<KeyFrame*> GetAllKeyFrames() const { return keyframes; }  /* include/Map.h:58 */
+};
+
+struct Options {
+    int device = 0;
+    int covisN = SDM_COVISN_DEFAULT; /* PM.h:38 */
+    int max_keyframes = 64;          /* device slots; least-recently-used keyframes are evicted */
+};
+
+}  // namespace sdm
+
+class ProbabilityMapping {
+public:
+    struct depthHo { /* PM.h:64-70 (Pw is never written by PM.cc) */
+        depthHo() : depth(0.0f), sigma(0.0f), supported(false) { Pw[0] = Pw[1] = Pw[2] = 0.0f; }
+        float depth;
+        float sigma;
+        bool supported;
+        float Pw[3];
+    };
+
+    explicit ProbabilityMapping(sdm::Map* pMap, const sdm::Options& opt = sdm::Options()); /* PM.h:72 */
+    ~ProbabilityMapping();
+
+    void SemiDenseRecon(sdm::KeyFrame* kf);                                               /* PM.h:75 */
+    void StereoSearchConstraints(sdm::KeyFrame* kf, float* min_depth, float* max_depth);  /* PM.h:77 */
+    void EpipolarSearch(sdm::KeyFrame* kf1, sdm::KeyFrame* kf2, const int x, const int y, float pixel,
+                        float min_depth, float max_depth, depthHo* dh, const float F12[9], float& best_u,
+                        float& best_v, float th_pi, float rot);                            /* PM.h:79 */
+    void GetSearchRange(float& umin, float& umax, int px, int py, float mind, float maxd, sdm::KeyFrame* kf,
+                        sdm::KeyFrame* kf2);                                               /* PM.h:80 */
+    void InverseDepthHypothesisFusion(const std::vector<depthHo>& h, depthHo& dist);      /* PM.h:83 */
+    void IntraKeyFrameDepthChecking(sdm::Mat<float>& depth_map, sdm::Mat<float>& depth_sigma,
+                                    const sdm::Mat<float> gradimg);                        /* PM.h:85 */
+    void IntraKeyFrameDepthGrowing(sdm::Mat<float>& depth_map, sdm::Mat<float>& depth_sigma,
+                                   const sdm::Mat<float> gradimg);                         /* PM.h:86 */
+    void UpdateSemiDensePointSet(sdm::KeyFrame* kf);                                      /* PM.h:88 */
+    void UpdateAllSemiDensePointSet();                                                    /* PM.h:89 */
+    void InterKeyFrameDepthChecking(sdm::KeyFrame* currentKf, std::vector<sdm::KeyFrame*> neighbors); /* PM.h:91 */
+
+    /* PM.cc:972-986 (private in the reference; public here so tests can reach it) */
+    void ComputeFundamental(sdm::KeyFrame* pKF1, sdm::KeyFrame* pKF2, float F12[9]);
+    /* PM.cc:100-132: "v x y z" lines for sigma <= 0.01 and rho > 1e-6; returns the vertex count */
+    long SavePointCloudObj(const char* path);
+    bool ok() const { return ctx_ != nullptr; }
+
+private:
+    int SlotOf(sdm::KeyFrame* kf);   /* uploads the keyframe on first use */
+    bool Ensure(int W, int H);
+    void PushDepth(sdm::KeyFrame* kf, int slot);
+    std::vector<sdm::KeyFrame*> PickNeighbours(sdm::KeyFrame* kf);  /* PM.cc:151-160 */
+
+    sdm::Map* mpMap;
+    sdm::Options opt_;
+    sdm_ctx* ctx_ = nullptr;
+    int W_ = 0, H_ = 0;
+    std::map<sdm::KeyFrame*, int> slots_;
+    std::map<sdm::KeyFrame*, int> depth_on_device_;  /* 1 = the slot's depth map equals kf->depth_map_ */
+    std::vector<sdm::KeyFrame*> slot_owner_;
+    std::vector<unsigned long> slot_use_;
+    unsigned long tick_ = 0;
+};
+
+#endif

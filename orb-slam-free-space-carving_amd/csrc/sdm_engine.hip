@@ -233,6 +233,19 @@ int push_meta(sdm_ctx* c, int slot)
     return SDM_OK;
 }
 
+// a keyframe uploaded into a slot starts with fresh (zero) maps and no stage flags
+int reset_slot(sdm_ctx* c, int slot)
+{
+    c->has_depth[slot] = 0;
+    c->has_chk[slot] = 0;
+    c->recon_lambdaG[slot] = std::nanf("");
+    c->act_lambdaG[slot] = std::nanf("");
+    HIP_TRY(hipMemsetAsync(c->pool + (long long)slot * c->P, 0, sizeof(float2) * c->P, c->stream));
+    HIP_TRY(hipMemsetAsync(c->chk + (long long)slot * c->P, 0, sizeof(float) * c->P, c->stream));
+    if (c->xyz) HIP_TRY(hipMemsetAsync(c->xyz + (long long)slot * c->P * 3, 0, sizeof(float) * 3 * c->P, c->stream));
+    return SDM_OK;
+}
+
 void fill_meta(KfMeta& m, const float K[4], const float Tcw[12])
 {
     m.fx = K[0];
@@ -505,6 +518,7 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     if (rc) return rc;
     if (!im || !grad || !theta || !K || !Tcw) return fail(SDM_EINVAL, "null input plane");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = reset_slot(c, slot))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_im, im, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_grad, grad, sizeof(float) * c->P, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_theta, theta, sizeof(float) * c->P, hipMemcpyHostToDevice, c->stream));
@@ -523,6 +537,7 @@ int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], 
     if (rc) return rc;
     if (!im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = reset_slot(c, slot))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_im, im, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
     KfMeta& m = c->h_meta[slot];
     fill_meta(m, K, Tcw);
@@ -537,6 +552,7 @@ int sdm_upload_image_device(sdm_ctx* c, int slot, const void* d_im, const float 
     if (rc) return rc;
     if (!d_im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = reset_slot(c, slot))) return rc;
     KfMeta& m = c->h_meta[slot];
     fill_meta(m, K, Tcw);
     m.uploaded = 1;

@@ -1,0 +1,366 @@
+// host/ProbabilityMapping.cc -- the reference's ProbabilityMapping class surface
+// (include/sdm/ProbabilityMapping.h) forwarding to the C ABI of the MI355X engine (include/sdm_c.h).
+//
+// Control flow follows /root/reference/src/Modeler/ProbabilityMapping.cc ("PM.cc") function by
+// function; every numeric step happens on the GPU.  This file only: picks neighbours (PM.cc:151-160),
+// derives the per-neighbour in-plane rotation and the depth prior from ORB data (host helpers of the C
+// ABI), keeps keyframes resident in device slots, and mirrors results into the KeyFrame members the
+// reference mutates (depth_map_, depth_sigma_, SemiDensePointSets_, the flags).
+#include "sdm/ProbabilityMapping.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "sdm_c.h"
+
+namespace {
+void report(const char* where)
+{
+    // same convention as the Modeler code around the seam: print and carry on
+    std::cerr << "ProbabilityMapping::" << where << ": " << sdm_last_error() << std::endl;
+}
+}  // namespace
+
+ProbabilityMapping::ProbabilityMapping(sdm::Map* pMap, const sdm::Options& opt) : mpMap(pMap), opt_(opt) {}
+
+ProbabilityMapping::~ProbabilityMapping()
+{
+    if (ctx_) sdm_destroy(ctx_);
+}
+
+bool ProbabilityMapping::Ensure(int W, int H)
+{
+    if (ctx_) {
+        if (W != W_ || H != H_) {
+            std::cerr << "ProbabilityMapping: image size " << W << "x" << H << " differs from the context's " << W_
+                      << "x" << H_ << std::endl;
+            return false;
+        }
+        return true;
+    }
+    sdm_config cfg;
+    sdm_default_config(&cfg);
+    cfg.device = opt_.device;
+    cfg.W = W;
+    cfg.H = H;
+    cfg.max_keyframes = std::max(opt_.max_keyframes, opt_.covisN + 1);
+    cfg.max_neighbours = std::max(1, std::min(opt_.covisN, SDM_MAX_NEIGHBOURS));
+    cfg.with_pointset = 1;
+    if (sdm_create(&ctx_, &cfg) != SDM_OK) {
+        report("ProbabilityMapping");
+        ctx_ = nullptr;
+        return false;
+    }
+    W_ = W;
+    H_ = H;
+    slot_owner_.assign(cfg.max_keyframes, nullptr);
+    slot_use_.assign(cfg.max_keyframes, 0);
+    return true;
+}
+
+// Device slot of a keyframe; uploads its inputs on first use (least-recently-used eviction).
+int ProbabilityMapping::SlotOf(sdm::KeyFrame* kf)
+{
+    if (!kf || kf->im_.empty()) return -1;
+    if (!Ensure(kf->im_.cols, kf->im_.rows)) return -1;
+    const float K[4] = {kf->fx, kf->fy, kf->cx, kf->cy};
+    auto it = slots_.find(kf);
+    if (it != slots_.end()) {
+        slot_use_[it->second] = ++tick_;
+        if (sdm_set_pose(ctx_, it->second, kf->Tcw) != SDM_OK) report("SlotOf");  // poses move under BA
+        return it->second;
+    }
+    int slot = 0;
+    for (size_t s = 0; s < slot_owner_.size(); s++) {
+        if (!slot_owner_[s]) {
+            slot = (int)s;
+            break;
+        }
+        if (slot_use_[s] < slot_use_[slot]) slot = (int)s;
+    }
+    if (slot_owner_[slot]) {
+        slots_.erase(slot_owner_[slot]);
+        depth_on_device_.erase(slot_owner_[slot]);
+    }
+    int rc;
+    if (kf->GradImg.empty() || kf->GradTheta.empty()) {
+        // the pre-processing the reference leaves to KeyFrame (GradImg/GradTheta/I_stddev), on the GPU
+        rc = sdm_upload_image(ctx_, slot, kf->im_.ptr(), K, kf->Tcw);
+        if (rc == SDM_OK) {
+            kf->GradImg = sdm::Mat<float>(H_, W_);
+            kf->GradTheta = sdm::Mat<float>(H_, W_);
+            rc = sdm_download_inputs(ctx_, slot, nullptr, kf->GradImg.ptr(), kf->GradTheta.ptr(), &kf->I_stddev);
+        }
+    } else {
+        rc = sdm_upload_keyframe(ctx_, slot, kf->im_.ptr(), kf->GradImg.ptr(), kf->GradTheta.ptr(), kf->I_stddev, K,
+                                 kf->Tcw);
+    }
+    if (rc != SDM_OK) {
+        report("SlotOf");
+        return -1;
+    }
+    if (kf->depth_map_.empty()) kf->depth_map_ = sdm::Mat<float>(H_, W_, 0.f);
+    if (kf->depth_sigma_.empty()) kf->depth_sigma_ = sdm::Mat<float>(H_, W_, 0.f);
+    if (kf->SemiDensePointSets_.empty()) kf->SemiDensePointSets_ = sdm::Mat<float>(H_, 3 * W_, 0.f);
+    slot_owner_[slot] = kf;
+    slot_use_[slot] = ++tick_;
+    slots_[kf] = slot;
+    depth_on_device_[kf] = 0;
+    return slot;
+}
+
+// make the slot's depth map equal to the keyframe's host maps
+void ProbabilityMapping::PushDepth(sdm::KeyFrame* kf, int slot)
+{
+    if (depth_on_device_[kf]) return;
+    if (sdm_upload_depth(ctx_, slot, kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK)
+        report("PushDepth");
+    else
+        depth_on_device_[kf] = 1;
+}
+
+// PM.cc:151-160 / 273-282: the first covisN covisible keyframes that are good and mapped
+std::vector<sdm::KeyFrame*> ProbabilityMapping::PickNeighbours(sdm::KeyFrame* kf)
+{
+    std::vector<sdm::KeyFrame*> out;
+    const std::vector<sdm::KeyFrame*>& all = kf->GetVectorCovisibleKeyFrames();
+    for (size_t i = 0; i < all.size(); i++) {
+        if ((int)out.size() >= opt_.covisN) break;
+        if (all[i]->isBad()) continue;
+        if (!all[i]->Mapped()) continue;
+        out.push_back(all[i]);
+    }
+    return out;
+}
+
+// PM.cc:370-383
+void ProbabilityMapping::StereoSearchConstraints(sdm::KeyFrame* kf, float* min_depth, float* max_depth)
+{
+    const std::vector<float>& d = kf->GetAllPointDepths();
+    if (sdm_stereo_search_constraints(d.data(), (int)d.size(), min_depth, max_depth) != SDM_OK)
+        report("StereoSearchConstraints");
+}
+
+// PM.cc:137-256 (per-keyframe reconstruction) followed by PM.cc:262-315 (inter-keyframe checking of
+// every keyframe whose neighbours are all reconstructed).
+void ProbabilityMapping::SemiDenseRecon(sdm::KeyFrame* kf)
+{
+    if (!kf || kf->isBad() || kf->semidense_flag_) return;  // PM.cc:141
+    std::vector<sdm::KeyFrame*> nbrs = PickNeighbours(kf);
+    if ((int)nbrs.size() < opt_.covisN) return;  // PM.cc:160
+    const int ref = SlotOf(kf);
+    if (ref < 0) return;
+    std::vector<int> nslots;
+    std::vector<float> rot;
+    for (size_t j = 0; j < nbrs.size(); j++) {
+        int s = SlotOf(nbrs[j]);
+        if (s < 0) return;
+        nslots.push_back(s);
+        // PM.cc:170-179: median in-plane rotation over shared map points, 0 without covisibility
+        rot.push_back(sdm_median_rot_in_plane(kf->map_point_ids.data(), kf->keypoint_angles.data(),
+                                              (int)std::min(kf->map_point_ids.size(), kf->keypoint_angles.size()),
+                                              nbrs[j]->map_point_ids.data(), nbrs[j]->keypoint_angles.data(),
+                                              (int)std::min(nbrs[j]->map_point_ids.size(),
+                                                            nbrs[j]->keypoint_angles.size())));
+    }
+    slot_use_[ref] = ++tick_;  // keep the reference resident while its neighbours are uploaded
+    float min_depth = 0.f, max_depth = 0.f;
+    StereoSearchConstraints(kf, &min_depth, &max_depth);  // PM.cc:184
+    if (sdm_recon(ctx_, 1, &ref, (int)nslots.size(), nslots.data(), rot.data(), &min_depth, &max_depth) != SDM_OK) {
+        report("SemiDenseRecon");
+        return;
+    }
+    if (sdm_download_depth(ctx_, ref, kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK) {
+        report("SemiDenseRecon");
+        return;
+    }
+    depth_on_device_[kf] = 1;
+    kf->semidense_flag_ = true;  // PM.cc:244
+
+    // PM.cc:262-315
+    if (!mpMap) return;
+    std::vector<sdm::KeyFrame*> vpKFs = mpMap->GetAllKeyFrames();
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        sdm::KeyFrame* k = vpKFs[i];
+        if (k->isBad() || k->interKF_depth_flag_) continue;
+        if (!k->semidense_flag_) continue;
+        std::vector<sdm::KeyFrame*> neighbors = PickNeighbours(k);
+        if ((int)neighbors.size() < opt_.covisN) continue;
+        int num_depth_kf = 0;
+        for (size_t j = 0; j < neighbors.size(); j++)
+            if (neighbors[j]->semidense_flag_) num_depth_kf++;
+        if (num_depth_kf < opt_.covisN) continue;  // PM.cc:298
+        InterKeyFrameDepthChecking(k, neighbors);
+        UpdateSemiDensePointSet(k);
+        k->interKF_depth_flag_ = true;  // PM.cc:306
+    }
+}
+
+// PM.cc:628-799, in place on currentKf->depth_map_
+void ProbabilityMapping::InterKeyFrameDepthChecking(sdm::KeyFrame* currentKf, std::vector<sdm::KeyFrame*> neighbors)
+{
+    if (!currentKf || neighbors.empty()) return;
+    const int ref = SlotOf(currentKf);
+    if (ref < 0) return;
+    std::vector<int> nslots;
+    for (size_t j = 0; j < neighbors.size(); j++) {
+        int s = SlotOf(neighbors[j]);
+        if (s < 0) return;
+        PushDepth(neighbors[j], s);
+        nslots.push_back(s);
+    }
+    PushDepth(currentKf, ref);
+    if (sdm_inter_check(ctx_, 1, &ref, (int)nslots.size(), nslots.data(), /*commit=*/1) != SDM_OK ||
+        sdm_download_depth(ctx_, ref, currentKf->depth_map_.ptr(), nullptr) != SDM_OK)
+        report("InterKeyFrameDepthChecking");
+}
+
+// PM.cc:337-367
+void ProbabilityMapping::UpdateSemiDensePointSet(sdm::KeyFrame* kf)
+{
+    const int slot = SlotOf(kf);
+    if (slot < 0) return;
+    PushDepth(kf, slot);
+    if (sdm_pointset(ctx_, 1, &slot, /*source = depth map*/ 0) != SDM_OK ||
+        sdm_download_pointset(ctx_, slot, kf->SemiDensePointSets_.ptr()) != SDM_OK)
+        report("UpdateSemiDensePointSet");
+}
+
+// PM.cc:321-334
+void ProbabilityMapping::UpdateAllSemiDensePointSet()
+{
+    if (!mpMap) return;
+    std::vector<sdm::KeyFrame*> vpKFs = mpMap->GetAllKeyFrames();
+    if (vpKFs.size() < 10) return;
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        sdm::KeyFrame* kf = vpKFs[i];
+        if (kf->isBad() || !kf->interKF_depth_flag_) continue;
+        if (kf->poseChanged) {
+            UpdateSemiDensePointSet(kf);
+            kf->poseChanged = false;
+        }
+    }
+}
+
+// PM.cc:385-465.  `pixel`, `F12` and `th_pi` are, at the reference's only call site (PM.cc:213-214),
+// im_(y,x), ComputeFundamental(kf1,kf2) and GradTheta(y,x) of the same keyframes; the engine derives
+// them from the resident keyframes, so the arguments are accepted for signature parity only.
+void ProbabilityMapping::EpipolarSearch(sdm::KeyFrame* kf1, sdm::KeyFrame* kf2, const int x, const int y, float pixel,
+                                        float min_depth, float max_depth, depthHo* dh, const float F12[9],
+                                        float& best_u, float& best_v, float th_pi, float rot)
+{
+    (void)pixel;
+    (void)F12;
+    (void)th_pi;
+    const int s1 = SlotOf(kf1), s2 = SlotOf(kf2);
+    if (s1 < 0 || s2 < 0 || !dh) return;
+    float out[5];
+    if (sdm_epipolar_search(ctx_, s1, s2, x, y, min_depth, max_depth, rot, out) != SDM_OK) {
+        report("EpipolarSearch");
+        return;
+    }
+    if (out[2] != 0.f) {  // the reference leaves *dh untouched when no match is found
+        dh->depth = out[0];
+        dh->sigma = out[1];
+        dh->supported = true;
+        best_u = out[3];
+        best_v = out[4];
+    }
+}
+
+// PM.cc:877-910
+void ProbabilityMapping::GetSearchRange(float& umin, float& umax, int px, int py, float mind, float maxd,
+                                        sdm::KeyFrame* kf, sdm::KeyFrame* kf2)
+{
+    const int s1 = SlotOf(kf), s2 = SlotOf(kf2);
+    if (s1 < 0 || s2 < 0) return;
+    if (sdm_search_range(ctx_, s1, s2, px, py, mind, maxd, &umin, &umax) != SDM_OK) report("GetSearchRange");
+}
+
+// PM.cc:598-626
+void ProbabilityMapping::InverseDepthHypothesisFusion(const std::vector<depthHo>& h, depthHo& dist)
+{
+    dist.depth = 0;
+    dist.sigma = 0;
+    dist.supported = false;
+    if (!ctx_) {
+        std::cerr << "ProbabilityMapping::InverseDepthHypothesisFusion: no device context yet" << std::endl;
+        return;
+    }
+    std::vector<float> rho(h.size()), sig(h.size());
+    for (size_t i = 0; i < h.size(); i++) {
+        rho[i] = h[i].depth;
+        sig[i] = h[i].sigma;
+    }
+    float out[3];
+    if (sdm_fuse(ctx_, rho.data(), sig.data(), (int)h.size(), out) != SDM_OK) {
+        report("InverseDepthHypothesisFusion");
+        return;
+    }
+    if (out[2] != 0.f) {
+        dist.depth = out[0];
+        dist.sigma = out[1];
+        dist.supported = true;
+    }
+}
+
+// PM.cc:486-547
+void ProbabilityMapping::IntraKeyFrameDepthChecking(sdm::Mat<float>& depth_map, sdm::Mat<float>& depth_sigma,
+                                                    const sdm::Mat<float> gradimg)
+{
+    if (!Ensure(depth_map.cols, depth_map.rows)) return;
+    if (sdm_intra_check_maps(ctx_, depth_map.ptr(), depth_sigma.ptr(), gradimg.empty() ? nullptr : gradimg.ptr()) !=
+        SDM_OK)
+        report("IntraKeyFrameDepthChecking");
+}
+
+// PM.cc:549-596
+void ProbabilityMapping::IntraKeyFrameDepthGrowing(sdm::Mat<float>& depth_map, sdm::Mat<float>& depth_sigma,
+                                                   const sdm::Mat<float> gradimg)
+{
+    if (!Ensure(depth_map.cols, depth_map.rows)) return;
+    if (sdm_intra_grow_maps(ctx_, depth_map.ptr(), depth_sigma.ptr(), gradimg.ptr()) != SDM_OK)
+        report("IntraKeyFrameDepthGrowing");
+}
+
+// PM.cc:972-986
+void ProbabilityMapping::ComputeFundamental(sdm::KeyFrame* pKF1, sdm::KeyFrame* pKF2, float F12[9])
+{
+    const int s1 = SlotOf(pKF1), s2 = SlotOf(pKF2);
+    if (s1 < 0 || s2 < 0) return;
+    if (sdm_pair_geometry(ctx_, s1, s2, F12, nullptr, nullptr) != SDM_OK) report("ComputeFundamental");
+}
+
+// PM.cc:100-132
+long ProbabilityMapping::SavePointCloudObj(const char* path)
+{
+    std::ofstream out(path, std::ios::out);
+    if (!out) {
+        std::cerr << "Failed to save points on line" << std::endl;
+        return -1;
+    }
+    long n = 0;
+    if (!mpMap) return 0;
+    std::vector<sdm::KeyFrame*> vpKFs = mpMap->GetAllKeyFrames();
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        sdm::KeyFrame* kf = vpKFs[i];
+        if (kf->isBad() || !kf->semidense_flag_ || !kf->interKF_depth_flag_) continue;
+        for (int y = 0; y < kf->im_.rows; y++)
+            for (int x = 0; x < kf->im_.cols; x++) {
+                if (kf->depth_sigma_.at(y, x) > 0.01) continue;
+                if (kf->depth_map_.at(y, x) > 0.000001) {
+                    out << "v " + std::to_string(kf->SemiDensePointSets_.at(y, 3 * x)) + " " +
+                               std::to_string(kf->SemiDensePointSets_.at(y, 3 * x + 1)) + " " +
+                               std::to_string(kf->SemiDensePointSets_.at(y, 3 * x + 2))
+                        << std::endl;
+                    n++;
+                }
+            }
+    }
+    out.flush();
+    return n;
+}
