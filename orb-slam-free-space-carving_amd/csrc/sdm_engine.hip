@@ -588,10 +588,10 @@ int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* t
 // ---- K1..K3 ----------------------------------------------------------------------------------------------------
 static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots)
 {
-    StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);
     hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
                        c->d_ref_slots, n_ref);
     HIP_TRY(hipGetLastError());
+    StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);  // brackets exactly one k_search_fuse launch
     int max_chunks = 0;
     for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + K1_PX - 1) / K1_PX);
     if (max_chunks == 0) return SDM_OK;  // no pixel passes the gradient gate: the maps stay zero
