@@ -276,13 +276,15 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(hyp + (size_t)n * K1_PX);
     unsigned* pkey = reinterpret_cast<unsigned*>(pmask + BLOCK);
 
-    // XCD-aware decode: chunk c of every reference keyframe runs on XCD c % 8
+    // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
+    // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
+    // neighbour image are resident on that XCD at the same time and share one L2 fill.
     const int b = blockIdx.x;
-    const int cpx = (max_chunks + 7) >> 3;
     const int i8 = b >> 3;
-    const int ref = i8 / cpx;
-    const int chunk = (i8 - ref * cpx) * 8 + (b & 7);
-    if (ref >= n_ref) return;
+    const int cl = i8 / n_ref;
+    const int ref = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
     const RefConst rc = refs[ref];
     if (chunk * K1_PX >= rc.act_count) return;
     const int tid = threadIdx.x, p = tid & (K1_PX - 1);
@@ -652,11 +654,11 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __rest
                                                             const unsigned* __restrict__ act, float* __restrict__ chk)
 {
     const int b = blockIdx.x;
-    const int cpx = (max_chunks + 7) >> 3;
     const int i8 = b >> 3;
-    const int ref = i8 / cpx;
-    const int chunk = (i8 - ref * cpx) * 8 + (b & 7);
-    if (ref >= n_ref) return;
+    const int cl = i8 / n_ref;
+    const int ref = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
     const RefConst rc = refs[ref];
     const int t = chunk * BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
