@@ -125,6 +125,10 @@ int sdm_download_pointset(sdm_ctx *ctx, int slot, float *xyz);            /* H x
 /* device addresses for zero-copy interop (RCCL all-gather of per-keyframe {rho,sigma} maps):
  * the depth pool is [max_keyframes][H][W] of float2 {rho,sigma}. */
 void *sdm_depth_pool_ptr(sdm_ctx *ctx);
+/* The caller asserts that the depth maps of these slots are zero outside the keyframe's active-pixel
+ * set {inset pixels with GradImg >= lambdaG} -- true for every map SemiDenseRecon produced, e.g. maps
+ * restored through sdm_upload_depth or received by an all-gather.  Lets K2-K4 use their list kernels. */
+int sdm_assume_pipeline_maps(sdm_ctx *ctx, int n, const int *slots);
 
 /* ---- stand-alone map operations with the reference's signatures -------------------------------- */
 /* IntraKeyFrameDepthChecking(cv::Mat&, cv::Mat&, const cv::Mat) PM.h:85; host maps, in place. */

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("sdm_download_checked", C.c_int, [_ctx, C.c_int, _f32p]),
     ("sdm_download_pointset", C.c_int, [_ctx, C.c_int, _f32p]),
     ("sdm_depth_pool_ptr", C.c_void_p, [_ctx]),
+    ("sdm_assume_pipeline_maps", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_intra_grow_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_epipolar_search", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -291,6 +292,10 @@ class Engine:
         x = np.empty((self.H, 3 * self.W), np.float32)
         self._check(self.lib.sdm_download_pointset(self.ctx, slot, x.ctypes.data_as(_f32p)))
         return x
+
+    def assume_pipeline_maps(self, slots):
+        r, rp = _i32(np.asarray(slots).reshape(-1))
+        self._check(self.lib.sdm_assume_pipeline_maps(self.ctx, len(r), rp))
 
     def intra_check_maps(self, rho, sigma, grad=None):
         r = np.array(rho, dtype=np.float32, order="C")

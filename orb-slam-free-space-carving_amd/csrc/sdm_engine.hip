@@ -215,6 +215,10 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
                            c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, n_ref, n,
                            c->d_refs, c->d_pairs);
         HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_ref_setup, dim3(blocks_for(n_ref)), dim3(BLOCK), 0, c->stream, c->d_meta, c->d_ref_slots,
+                           c->d_act_count, n_ref, c->d_refs);
+        HIP_TRY(hipGetLastError());
     }
     return SDM_OK;
 }
@@ -658,6 +662,51 @@ static int stage_offsets(sdm_ctx* c, int n_ref, const int* ref_slots)
     return SDM_OK;
 }
 
+// K2/K3 on "pipeline" maps (zero outside the keyframe's active list: written by K1, or declared so by
+// sdm_assume_pipeline_maps).  RefConst (act_count, slot) of the staged batch is valid here.
+static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bool grow)
+{
+    int rc = stage_offsets(c, n_ref, ref_slots);
+    if (rc) return rc;
+    StageTimer tm(c, SDM_STAGE_INTRA);
+    const int K = c->cap_refs, cap = c->cfg.batch_capacity;
+    for (int first = 0; first < n_ref; first += cap) {
+        const int count = std::min(cap, n_ref - first);
+        int max_chunks = 0;
+        for (int r = 0; r < count; r++)
+            max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[first + r]] + BLOCK - 1) / BLOCK);
+        if (max_chunks == 0) continue;
+        const int grid = 8 * ((max_chunks + 7) / 8) * count;
+        if (check) {
+            HIP_TRY(hipMemsetAsync(c->scratch, 0, sizeof(float2) * c->P * count, c->stream));
+            hipLaunchKernelGGL(k_intra_list<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
+                               c->d_off, c->d_off + K, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act);
+            HIP_TRY(hipGetLastError());
+        } else {
+            for (int r = 0; r < count; r++)
+                HIP_TRY(hipMemcpyAsync(c->scratch + (long long)r * c->P, c->pool + c->h_off[first + r],
+                                       sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (grow) {
+            hipLaunchKernelGGL(k_intra_list<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
+                               c->d_off + K, c->d_off, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act);
+            HIP_TRY(hipGetLastError());
+        } else {
+            for (int r = 0; r < count; r++)
+                HIP_TRY(hipMemcpyAsync(c->pool + c->h_off[first + r], c->scratch + (long long)r * c->P,
+                                       sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    return SDM_OK;
+}
+
+static bool all_pipeline_maps(sdm_ctx* c, int n_ref, const int* ref_slots)
+{
+    for (int r = 0; r < n_ref; r++)
+        if (!(c->recon_lambdaG[ref_slots[r]] == c->dprm.lambdaG)) return false;
+    return true;
+}
+
 static int run_intra(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bool grow)
 {
     // K2 writes scratch, K3 writes back to the pool.  A lone pass is completed by a device copy.
@@ -689,7 +738,11 @@ int sdm_intra_check(sdm_ctx* c, int n_ref, const int* ref_slots)
     if (!c) return fail(SDM_EINVAL, "null context");
     int rc = stage_tables(c, n_ref, ref_slots, 0, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    if ((rc = run_intra(c, n_ref, ref_slots, true, false))) return rc;
+    if (all_pipeline_maps(c, n_ref, ref_slots))
+        rc = run_intra_lists(c, n_ref, ref_slots, true, false);
+    else
+        rc = run_intra(c, n_ref, ref_slots, true, false);
+    if (rc) return rc;
     return tables_staged(c);
 }
 
@@ -698,7 +751,11 @@ int sdm_intra_grow(sdm_ctx* c, int n_ref, const int* ref_slots)
     if (!c) return fail(SDM_EINVAL, "null context");
     int rc = stage_tables(c, n_ref, ref_slots, 0, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    if ((rc = run_intra(c, n_ref, ref_slots, false, true))) return rc;
+    if (all_pipeline_maps(c, n_ref, ref_slots))
+        rc = run_intra_lists(c, n_ref, ref_slots, false, true);
+    else
+        rc = run_intra(c, n_ref, ref_slots, false, true);
+    if (rc) return rc;
     return tables_staged(c);
 }
 
@@ -711,7 +768,7 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
-    if ((rc = run_intra(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
+    if ((rc = run_intra_lists(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
     for (int r = 0; r < n_ref; r++) {
         c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244
         c->recon_lambdaG[ref_slots[r]] = c->dprm.lambdaG;
@@ -839,6 +896,20 @@ int sdm_download_pointset(sdm_ctx* c, int slot, float* xyz)
 }
 
 void* sdm_depth_pool_ptr(sdm_ctx* c) { return c ? (void*)c->pool : nullptr; }
+
+int sdm_assume_pipeline_maps(sdm_ctx* c, int n, const int* slots)
+{
+    if (!c || !slots) return fail(SDM_EINVAL, "null argument");
+    for (int i = 0; i < n; i++) {
+        int rc = check_slot(c, slots[i], true);
+        if (rc) return rc;
+        if (!(c->act_lambdaG[slots[i]] == c->dprm.lambdaG))
+            if ((rc = build_active(c, slots[i]))) return rc;
+        c->recon_lambdaG[slots[i]] = c->dprm.lambdaG;
+        c->has_depth[slots[i]] = 1;
+    }
+    return SDM_OK;
+}
 
 // ---- stand-alone map operations (PM.h:85-86 signatures): scratch slot 0 in, slot 1 out -------------------------------------
 static int intra_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad, bool grow)

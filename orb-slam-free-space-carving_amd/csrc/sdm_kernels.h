@@ -193,6 +193,25 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     }
 }
 
+// RefConst table for stages without neighbours (K2/K3/K5 on slots)
+__global__ void k_ref_setup(const KfMeta* __restrict__ meta, const int* __restrict__ ref_slots,
+                            const int* __restrict__ act_counts, int n_ref, RefConst* __restrict__ refs)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ref) return;
+    KfMeta m = meta[ref_slots[r]];
+    RefConst rc;
+    rc.slot = ref_slots[r];
+    rc.fx = m.fx;
+    rc.fy = m.fy;
+    rc.cx = m.cx;
+    rc.cy = m.cy;
+    rc.mind = 0.f;
+    rc.maxd = 0.f;
+    rc.act_count = act_counts[ref_slots[r]];
+    refs[r] = rc;
+}
+
 // ---- active-pixel lists ------------------------------------------------------------------------------------
 // The reference skips every pixel with GradImg < lambdaG (PM.cc:201), ~80 % of an image, and every
 // later stage only ever touches the survivors.  That set depends on the keyframe's own image only,
@@ -534,6 +553,92 @@ __global__ __launch_bounds__(BLOCK) void k_intra_grow(const float2* __restrict__
         int x = tx0 + (L & (TILE_W - 1)), y = ty0 + (L >> 6);
         if (x < W && y < H) out[y * W + x] = outv[L];
     }
+}
+
+// ---- K2/K3, pipeline form ---------------------------------------------------------------------------------
+// Inside SemiDenseRecon the map K2 reads was just written by K1: it is zero outside the keyframe's
+// active-pixel list, and K2/K3 only ever modify listed pixels (K2: pixels with rho > 1e-6; K3:
+// pixels with GradImg >= lambdaG).  So both passes run one thread per list entry with the 3x3
+// neighbourhood gathered straight from the (L2-resident) map; `dst` must be zero outside the list
+// (K2: a cleared scratch map, K3: the K1 map itself).  jobs: src/dst offsets per reference.
+__device__ __forceinline__ float2 intra_check_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c)
+{
+    float pjsj = 0.f, rsj = 0.f, tmin = 0.f;  // GetFusion overload B streamed, PM.cc:947-970
+    int cnt = 0;
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (k == 4) continue;
+        v[k < 4 ? k : k - 1] = in[(y + k / 3 - 1) * W + x + (k % 3) - 1];
+    }
+    const float rc = safe_rcp_sq(c.y);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // raster order, PM.cc:504-521
+        if ((double)v[k].x > 0.000001 && chi_test_fast(v[k].x, c.x, v[k].y, c.y, safe_rcp_sq(v[k].y), rc)) {
+            if (cnt == 0) tmin = v[k].y;
+            fusion_accum(v[k].x, v[k].y, pjsj, rsj);
+            if ((double)v[k].y * (double)v[k].y < (double)tmin * (double)tmin) tmin = v[k].y;
+            cnt++;
+        }
+    }
+    if (cnt == 0) tmin = c.y;
+    fusion_accum(c.x, c.y, pjsj, rsj);  // itself, last: PM.cc:522
+    if ((double)c.y * (double)c.y < (double)tmin * (double)tmin) tmin = c.y;
+    cnt++;
+    return (cnt >= 3) ? make_float2(pjsj / rsj, tmin) : make_float2(0.f, 0.f);  // PM.cc:524-536
+}
+
+__device__ __forceinline__ float2 intra_grow_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c)
+{
+    float pjsj = 0.f, rsj = 0.f, smin = 0.f;  // GetFusion overload A, PM.cc:926-945
+    int cnt = 0;
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        if (k == 4) continue;
+        v[k < 4 ? k : k - 1] = in[(y + k / 3 - 1) * W + x + (k % 3) - 1];
+    }
+    const float rc = safe_rcp_sq(c.y);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (chi_test_fast(v[k].x, c.x, v[k].y, c.y, safe_rcp_sq(v[k].y), rc)) {  // PM.cc:571
+            if (cnt == 0) smin = v[k].y;
+            fusion_accum(v[k].x, v[k].y, pjsj, rsj);
+            if (v[k].y < smin) smin = v[k].y;
+            cnt++;
+        }
+    }
+    return (cnt >= 2) ? make_float2(pjsj / rsj, smin) : c;  // PM.cc:581-587
+}
+
+template <bool GROW>
+__global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__ src_base, float2* __restrict__ dst_base,
+                                                      const long long* __restrict__ src_off,
+                                                      const long long* __restrict__ dst_off,
+                                                      const RefConst* __restrict__ refs, int first, int n_ref, int W,
+                                                      int max_chunks, long long plane, const unsigned* __restrict__ act)
+{
+    const int b = blockIdx.x;
+    const int i8 = b >> 3;
+    const int cl = i8 / n_ref;
+    const int r = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
+    const RefConst rc = refs[first + r];
+    const int t = chunk * BLOCK + threadIdx.x;
+    if (t >= rc.act_count) return;
+    const unsigned xy = act[(long long)rc.slot * plane + t];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const float2* __restrict__ in = src_base + src_off[first + r];
+    float2* __restrict__ out = dst_base + dst_off[first + r];
+    const float2 c = in[y * W + x];
+    float2 o = c;
+    if (GROW) {
+        if ((double)c.x < 0.000001) o = intra_grow_pixel(in, W, x, y, c);  // PM.cc:560 (gradient gate = list)
+    } else {
+        if ((double)c.x > 0.000001) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
+    }
+    out[y * W + x] = o;
 }
 
 // ---- K4: InterKeyFrameDepthChecking, PM.cc:628-799 ------------------------------------------------------

@@ -226,6 +226,52 @@ def test_intra_check_and_grow_maps(pkg, oracle, gpu_ok, shape):
     eng.close()
 
 
+def test_list_kernels_on_declared_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
+    """K2/K3/K4 list kernels (one thread per active-list entry) on crafted maps that are zero outside
+    the active set but otherwise adversarial: NaN/Inf/zero sigma, rho~0 with sigma>0 (growing live)"""
+    seq, n = seq_mid, 7
+    eng = make_engine(pkg, seq, n)
+    rng = np.random.default_rng(21)
+    rho, sig = {}, {}
+    for k in range(seq.n_kf):
+        active = np.zeros((seq.H, seq.W), bool)
+        active[2:-2, 2:-2] = seq.grad[k][2:-2, 2:-2] >= 8
+        r, s = crafted_maps(rng, seq.H, seq.W, density=0.7)
+        r[r > 0] = (seq.gt[k] * (1 + 0.01 * rng.standard_normal((seq.H, seq.W))).astype(np.float32))[r > 0]
+        r[~active] = 0
+        s[~active] = 0
+        rho[k], sig[k] = r, s
+        eng.upload_depth(k, r, s)
+    refs = list(range(seq.n_kf))
+    eng.assume_pipeline_maps(refs)
+    eng.intra_check(refs)
+    grown = 0
+    for k in refs:
+        o1, p1 = oracle.intra_check(rho[k], sig[k])
+        g = eng.download_depth(k)
+        assert_bit_equal(g[0], o1, "list K2 rho kf %d" % k)
+        assert_bit_equal(g[1], p1, "list K2 sigma kf %d" % k)
+        eng.upload_depth(k, rho[k], sig[k])
+    eng.assume_pipeline_maps(refs)
+    eng.intra_grow(refs)
+    for k in refs:
+        o2, p2 = oracle.intra_grow(rho[k], sig[k], seq.grad[k])
+        g = eng.download_depth(k)
+        assert_bit_equal(g[0], o2, "list K3 rho kf %d" % k)
+        assert_bit_equal(g[1], p2, "list K3 sigma kf %d" % k)
+        grown += int((o2.view(np.uint32) != rho[k].view(np.uint32)).sum())
+        eng.upload_depth(k, rho[k], sig[k])
+    assert grown > 10, "growing must be exercised by the list kernel"
+    eng.assume_pipeline_maps(refs)
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.inter_check(refs, nbrs)
+    for k in refs:
+        ref = oracle.inter_check(seq.okf[k], rho[k], [seq.okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                                 [sig[j] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), ref, "list K4 kf %d" % k)
+    eng.close()
+
+
 def test_growing_is_noop_on_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
     """after K1+K2 every rho<1e-6 pixel has sigma 0, so K3 changes nothing"""
     eng = make_engine(pkg, seq_mid, 7)
