@@ -173,7 +173,9 @@ int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long laun
                    int reset);
 /* device arithmetic self-tests: out[0] = mismatches (must be 0), out[1] = auxiliary count.
  * which 0: reciprocal+FMA division by theta_var vs plain division over all 2^32 float inputs;
- * which 1: reciprocal-prefiltered ChiTest vs the exact ChiTest around the 5.99 threshold. */
+ * which 1: reciprocal-prefiltered ChiTest vs the exact ChiTest around the 5.99 threshold;
+ * which 2: fast matching cost (PM.cc:436) vs the reference expression incl. rounding midpoints;
+ * which 3: closed-form angle gates (PM.cc:414-431) vs the reference statement. */
 int sdm_selftest(sdm_ctx *ctx, int which, unsigned long long out[2]);
 /* name of the device the context runs on, e.g. "gfx950" */
 const char *sdm_device_arch(sdm_ctx *ctx);

@@ -48,7 +48,7 @@ struct DevParams {  // sdm_params + host-precomputed (1/THETA), PM.cc:455-456
     double theta_var;
     double inv_theta;
     int fast_theta_div;  // x/theta_var via reciprocal + FMA correction (exhaustively verified for 0.23)
-    int pad;
+    int default_gates;   // lambdaL == 80 && lambdaTheta == 45: the closed-form angle gates apply
 };
 
 // x / d for a double x that was widened from a non-negative float, d = theta_var, r = RN(1/d).
@@ -217,6 +217,64 @@ __device__ __forceinline__ void search_range(float fx, float cx, float rxxp, flo
     if (umax > cols) umax = cols;
 }
 
+// ---- the two angle gates of the scan, PM.cc:414-431 -----------------------------------------------------
+// Reference statement (every step in float):
+//   d = theta2 - ref;  if (d >= 360) d -= 360;  if (d < 0) d += 360;  if (d > 180) d = 360 - d;
+//   gate 2 (ref = epipolar-line angle):  if (d > 90) d = 180 - d;  skip if d > lambdaL
+//   gate 3 (ref = theta_pi + rot):       skip if d > lambdaTheta
+__device__ __forceinline__ bool gate2_fails_ref(float d, float lambdaL)
+{
+    if (d >= 360) d -= 360;
+    if (d < 0) d += 360;
+    if (d > 180) d = 360 - d;
+    if (d > 90) d = 180 - d;
+    return d > lambdaL;
+}
+__device__ __forceinline__ bool gate3_fails_ref(float d, float lambdaTheta)
+{
+    if (d >= 360) d -= 360;
+    if (d < 0) d += 360;
+    if (d > 180) d = 360 - d;
+    return d > lambdaTheta;
+}
+// Closed forms, valid when d < 360 (any d below that, including -Inf; NaN excluded by the caller's
+// guard) and the thresholds are the defaults (80, 45).  With x = d + (d < 0 ? 360 : 0) -- the same
+// rounding as the reference's "d += 360" -- every later step is exact (Sterbenz), so
+//   gate 2 fails  <=>  x in (80,100) or (260,280)  <=>  |x-90| < 10  or  |x-270| < 10
+//   gate 3 fails  <=>  45 < x < 315
+// (x-90 and x-270 are exact wherever their magnitude is near 10).  sdm_selftest(3) compares both
+// forms with the reference statement over dense and boundary inputs.
+__device__ __forceinline__ float wrap_neg360(float d)
+{
+    unsigned neg = (unsigned)((int)__float_as_uint(d) >> 31);  // all ones iff the sign bit is set
+    return d + __uint_as_float(neg & 0x43B40000u);            // + 360.0f or + 0.0f
+}
+__device__ __forceinline__ bool gate2_fails_fast(float d)
+{
+    float x = wrap_neg360(d);
+    return (fabsf(x - 90.0f) < 10.0f) | (fabsf(x - 270.0f) < 10.0f);
+}
+__device__ __forceinline__ bool gate3_fails_fast(float d)
+{
+    float x = wrap_neg360(d);
+    return (x > 45.0f) & (x < 315.0f);
+}
+
+// ---- matching cost, PM.cc:436:  err = (float)((double)pe2 + (double)ge2 / THETA) ------------------------
+// Fast path: s = pe2 + ge2 * (1/THETA) in double differs from the reference's double sum by at most
+// a few ulp(double), so (float)s is the reference's value unless s lies within 2^-45 relative of a
+// float rounding midpoint (low 29 mantissa bits == 0x10000000 +- 256) or err is outside the normal
+// float range; those rare cases take the exact division.  sdm_selftest(2) checks it.
+__device__ __forceinline__ float match_cost(float pe2, float ge2, const DevParams& prm)
+{
+    double s = (double)pe2 + (double)ge2 * prm.inv_theta;
+    unsigned lo = (unsigned)__double2loint(s);
+    bool risky = (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) | !(s > 1.0e-30) | !(s < 1.0e30);
+    if (risky) s = (double)pe2 + div_theta((double)ge2, prm.theta_var, prm.inv_theta, prm.fast_theta_div);
+    return (float)s;
+}
+
+// (scan tuning macros)
 #ifndef SDM_BRANCHFREE_GATES
 #define SDM_BRANCHFREE_GATES 0
 #endif
@@ -324,51 +382,26 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             if (STATS && uj <= hi) st->candidates++;
             const float yf = yfs[k];
             const float4 r = rs[k];
-#if SDM_BRANCHFREE_GATES
-            // validity (PM.cc:408 + N3) and the three gates, evaluated branch-free
-            bool pass = (uj <= hi) & (yf >= 1.0f) & (yf < hlim);
-            pass &= !(r.x < prm.lambdaG);    // PM.cc:411
-            float ang_diff = r.y - th_line;  // PM.cc:415-421
-            if (ang_diff >= 360) ang_diff -= 360;
-            if (ang_diff < 0) ang_diff += 360;
-            if (ang_diff > 180) ang_diff = 360 - ang_diff;
-            if (ang_diff > 90) ang_diff = 180 - ang_diff;
-            pass &= !(ang_diff > prm.lambdaL);
-            float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
-            if (th_diff >= 360) th_diff -= 360;
-            if (th_diff < 0) th_diff += 360;
-            if (th_diff > 180) th_diff = 360 - th_diff;
-            pass &= !(th_diff > prm.lambdaTheta);
-            if (!pass) continue;
-#else
             if (!((uj <= hi) & (yf >= 1.0f) & (yf < hlim))) continue;  // PM.cc:408 + N3
             if (r.x < prm.lambdaG) continue;                            // PM.cc:411
-            float ang_diff = r.y - th_line;                             // PM.cc:415-421
-            if (ang_diff >= 360) ang_diff -= 360;
-            if (ang_diff < 0) ang_diff += 360;
-            if (ang_diff > 180) ang_diff = 360 - ang_diff;
-            if (ang_diff > 90) ang_diff = 180 - ang_diff;
-            if (ang_diff > prm.lambdaL) continue;
-            float th_diff = r.y - ang_pi_rot;  // PM.cc:427-431
-            if (th_diff >= 360) th_diff -= 360;
-            if (th_diff < 0) th_diff += 360;
-            if (th_diff > 180) th_diff = 360 - th_diff;
-            if (th_diff > prm.lambdaTheta) continue;
-#endif
-            {
-                if (STATS) st->gate_pass++;
-                const int vj = (int)yf;
-                float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
-                float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
-                float pe2 = pe * pe, ge2 = ge * ge;
-                float err = (float)((double)pe2 + div_theta((double)ge2, prm.theta_var, prm.inv_theta,
-                                                            prm.fast_theta_div));  // PM.cc:436
-                if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
-                    best_pixel = uj;
-                    old_err = err;
-                    best_pe = pe;
-                    best_ge = ge;
-                }
+            const float d2 = r.y - th_line;     // PM.cc:415-416
+            const float d3 = r.y - ang_pi_rot;  // PM.cc:427
+            bool fail;
+            if (prm.default_gates && (d2 < 360.0f) & (d3 < 360.0f))
+                fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+            else
+                fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
+            if (fail) continue;  // PM.cc:421,431
+            if (STATS) st->gate_pass++;
+            const int vj = (int)yf;
+            float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
+            float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
+            float err = match_cost(pe * pe, ge * ge, prm);  // PM.cc:436
+            if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
+                best_pixel = uj;
+                old_err = err;
+                best_pe = pe;
+                best_ge = ge;
             }
         }
     }

@@ -114,7 +114,7 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.theta_var = c->prm.theta_var;
     c->dprm.inv_theta = 1 / c->prm.theta_var;  // (1/THETA), PM.cc:455
     c->dprm.fast_theta_div = (c->prm.theta_var == 0.23) ? 1 : 0;
-    c->dprm.pad = 0;
+    c->dprm.default_gates = (c->prm.lambdaL == 80.0f && c->prm.lambdaTheta == 45.0f) ? 1 : 0;
 }
 
 // (re)build the active-pixel list of a slot for the current lambdaG; reads the count back
@@ -1072,6 +1072,11 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     } else if (which == 1) {
         hipLaunchKernelGGL(k_selftest_chi, dim3(1024), dim3(BLOCK), 0, c->stream, 1024, c->d_stats + 5,
                            c->d_stats + 6);
+    } else if (which == 2) {
+        hipLaunchKernelGGL(k_selftest_cost, dim3(1024), dim3(BLOCK), 0, c->stream, c->dprm, 2048, c->d_stats + 5,
+                           c->d_stats + 6);
+    } else if (which == 3) {
+        hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else {
         return fail(SDM_EINVAL, "unknown selftest");
     }

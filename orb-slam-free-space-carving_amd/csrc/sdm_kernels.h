@@ -944,4 +944,95 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_chi(int iters, unsigned long
     }
 }
 
+// which = 2: match_cost (reciprocal fast path + mid-point fallback) vs the reference expression.
+// Operands: random squares, plus pairs CONSTRUCTED so that the double sum lands on / next to a float
+// rounding midpoint (forces the fallback and the near-miss cases on both sides).
+__global__ __launch_bounds__(BLOCK) void k_selftest_cost(DevParams prm, int iters, unsigned long long* __restrict__ bad,
+                                                         unsigned long long* __restrict__ risky_hits)
+{
+    unsigned s = 0x85EBCA6Bu * (blockIdx.x * BLOCK + threadIdx.x + 1);
+    unsigned long long cnt = 0, hits = 0;
+    for (int i = 0; i < iters; i++) {
+        float ge = ((xs32(s) >> 8) * (1.0f / 16777216.0f)) * 60.0f;
+        float ge2 = ge * ge;
+        float pe2;
+        if (i & 1) {
+            float pe = ((xs32(s) >> 8) * (1.0f / 16777216.0f)) * 255.0f;
+            pe2 = pe * pe;
+        } else {
+            // choose a small pe2 so that pe2 + ge2/theta sits within a few double-ulps of the first
+            // float rounding midpoint above q = ge2/theta (pe2 is tiny, so its own grid is fine enough)
+            double q = (double)ge2 / prm.theta_var;
+            float lowf = (float)q;
+            if ((double)lowf > q) lowf = __uint_as_float(__float_as_uint(lowf) - 1u);
+            float upf = __uint_as_float(__float_as_uint(lowf) + 1u);
+            double mid = ((double)lowf + (double)upf) * 0.5;
+            if (mid < q) mid = ((double)upf + (double)__uint_as_float(__float_as_uint(upf) + 1u)) * 0.5;
+            pe2 = (float)(mid - q);
+            int k = (int)(xs32(s) % 5u) - 2;
+            if (pe2 > 1e-30f) pe2 = __uint_as_float(__float_as_uint(pe2) + k);
+        }
+        float ref = (float)((double)pe2 + (double)ge2 / prm.theta_var);
+        float got = match_cost(pe2, ge2, prm);
+        if (!(ref == got || (ref != ref && got != got))) cnt++;
+        double sfast = (double)pe2 + (double)ge2 * prm.inv_theta;
+        unsigned lo = (unsigned)__double2loint(sfast);
+        if (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) hits++;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        hits += __shfl_down(hits, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        if (hits) atomicAdd(risky_hits, hits);
+    }
+}
+
+// which = 3: closed-form angle gates vs the reference statement, for d = theta2 - ref over
+// (a) every float in [-400, 400] visited with a stride, (b) every float within 64 ulps of each
+// boundary (+-45, +-80, +-100, +-260, +-280, +-315, 0, +-180, +-360), (c) random theta pairs.
+__global__ __launch_bounds__(BLOCK) void k_selftest_gates(unsigned long long* __restrict__ bad,
+                                                          unsigned long long* __restrict__ tested)
+{
+    const unsigned gid = blockIdx.x * BLOCK + threadIdx.x, nthreads = gridDim.x * BLOCK;
+    unsigned long long cnt = 0, n = 0;
+    auto check = [&](float d) {
+        if (!(d < 360.0f)) return;  // the kernel's guard routes these to the reference form
+        if (gate2_fails_fast(d) != gate2_fails_ref(d, 80.0f)) cnt++;
+        if (gate3_fails_fast(d) != gate3_fails_ref(d, 45.0f)) cnt++;
+        n++;
+    };
+    // (a) strided sweep of the positive and negative float line up to |d| = 400 (0x43C80000)
+    for (unsigned u = gid; u <= 0x43C80000u; u += nthreads) {
+        check(__uint_as_float(u));
+        check(__uint_as_float(u | 0x80000000u));
+    }
+    // (b) boundary neighbourhoods
+    const float bnd[12] = {0.f, 45.f, 80.f, 90.f, 100.f, 180.f, 260.f, 270.f, 280.f, 315.f, 360.f, 135.f};
+    if (gid < 12 * 4096) {
+        unsigned base = __float_as_uint(bnd[gid / 4096]);
+        int k = (int)(gid % 4096) - 2048;
+        float v = __uint_as_float(base + k);
+        check(v);
+        check(-v);
+    }
+    // (c) differences of in-range thetas
+    unsigned s = 0xC2B2AE35u * (gid + 1);
+    for (int i = 0; i < 64; i++) {
+        float t2 = ((xs32(s) >> 8) * (1.0f / 16777216.0f)) * 360.0f;
+        float rf = ((xs32(s) >> 8) * (1.0f / 16777216.0f)) * 360.0f;
+        check(t2 - rf);
+    }
+    check(-__builtin_inff());
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        n += __shfl_down(n, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        atomicAdd(tested, n);
+    }
+}
+
 }  // namespace sdm

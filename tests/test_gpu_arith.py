@@ -19,3 +19,22 @@ def test_chi_prefilter_is_exact(pkg, gpu_ok):
     assert bad == 0
     assert inband > 1000, "test must hit the uncertainty band"
     eng.close()
+
+
+def test_match_cost_fast_path_is_exact(pkg, gpu_ok):
+    """err = (float)(pe2 + ge2/THETA): reciprocal path + mid-point fallback == the reference expression,
+    including operands constructed to land on float rounding midpoints"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, risky = eng.selftest(2)
+    assert bad == 0
+    assert risky > 1000, "the fallback must be exercised"
+    eng.close()
+
+
+def test_angle_gates_closed_form(pkg, gpu_ok):
+    """closed-form gates 2/3 == the reference's wrap-and-compare statement for every tested difference"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, tested = eng.selftest(3)
+    assert bad == 0
+    assert tested > 2 ** 31
+    eng.close()
