@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--disparity", type=float, default=2.6, help="adjacent-keyframe disparity (px): scan-length knob")
     ap.add_argument("--cpu-kfs", type=int, default=12, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N>1 exchange of {rho,sigma} maps between K3 and K4 (shard.py)")
     return ap.parse_args()
 
 
@@ -102,9 +104,22 @@ def main():
         eng.synchronize()
         t_h2d = (time.perf_counter() - t0) / len(ks)
 
+    nb_of = dict(zip(own, nbrs))
+    boundary, interior = pl["boundary"], pl["interior"]
+
     def step():
-        eng.recon(own, nbrs, min_d, max_d)
-        shard.allgather_depth(pool, pl["first"], pl["count"])
+        if world > 1 and args.exchange == "halo" and boundary:
+            # boundary keyframes first; their maps travel to the adjacent ranks (point-to-point over
+            # xGMI) while the interior keyframes are reconstructed
+            eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+            works = shard.exchange_halo_async(pool, pl)
+            if interior:
+                eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
+            shard.wait_all(works)
+        else:
+            eng.recon(own, nbrs, min_d, max_d)
+            if world > 1:
+                shard.allgather_depth(pool, pl["first"], pl["count"])
         eng.inter_check(own, nbrs, commit=False)
         eng.pointset(own, source=1)
 
@@ -148,8 +163,10 @@ def main():
     ms_step = dt / args.steps * 1e3
     value = P * n_total * args.steps / dt / 1e6
     k1_ms, k1_n = timing["search_fuse"]
+    # algorithmic bytes of k_search_fuse (P*(17+9N) per reference keyframe) over the
+    # keyframes one launch covers; a step may split its keyframes over 2 launches (boundary/interior)
     k1_avg_ms = k1_ms / max(k1_n, 1)
-    k1_bytes = P * (17 + 9 * N) * len(own)  # algorithmic bytes of ONE k_search_fuse launch
+    k1_bytes = P * (17 + 9 * N) * len(own) * args.steps / max(k1_n, 1)
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
     out = {
         "metric": "Mpix*KF/s fused (%dx%dxN_KF)" % (W, H),
@@ -167,7 +184,8 @@ def main():
         "config": {
             "workload": "%dx%d, %d keyframes/GPU x %d covisible neighbours, synthetic gradient images "
                         "(BASELINE.json configs[1])" % (W, H, args.kfs, N),
-            "stages": "SemiDenseRecon(K1-K3)+allgather+InterKFCheck(K4)+PointSet(K5)",
+            "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5)" %
+                      ("no exchange (1 GPU)" if world == 1 else args.exchange + " exchange of {rho,sigma} maps (RCCL)"),
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
             "parallelism": "keyframe-block x%d" % world, "arch": arch,
         },

@@ -3,39 +3,111 @@
 K1-K3 (SemiDenseRecon, PM.cc:137-256) of keyframe k read only immutable inputs of k and its
 covisible neighbours; K4 (InterKeyFrameDepthChecking, PM.cc:628-799) needs the neighbours'
 FINISHED {rho, sigma} maps (the reference gates on that at PM.cc:292-298).  So keyframes shard as
-contiguous blocks, one block per GPU, with exactly one exchange step between K3 and K4: an
-all-gather of the per-keyframe {rho, sigma} maps (RCCL over xGMI through torch.distributed).
-Slot numbering is GLOBAL (slot == keyframe index) on every rank, so the gathered pool needs no
-re-indexing and the depth pool is all-gathered in place.
+contiguous blocks, one block per GPU, with exactly one exchange step between K3 and K4.
+
+Slot numbering is GLOBAL (slot == keyframe index) on every rank and the depth pool is one torch
+tensor [n_total, H, W, 2] handed to the engine as `ext_depth_pool`, so exchanged maps land where K4
+reads them and no re-indexing or staging copy is needed.  Two exchange forms:
+
+  halo (default)  each rank receives only the maps its K4 will read (the covisible neighbours that
+                  live on other ranks: N/2 keyframes from each adjacent block for an index-local
+                  covisibility graph) with batched point-to-point send/recv.  xGMI is point-to-point,
+                  so this moves 2 x (N/2) x 8P bytes per rank over two direct links, independent of
+                  the number of GPUs, and it is issued right after the boundary keyframes are
+                  reconstructed so it overlaps the reconstruction of the interior ones.
+  allgather       the whole pool, in place (BASELINE.json's wording); (world-1) x block bytes per rank.
 """
 import torch
 import torch.distributed as dist
 
 
 def block_partition(n_total, world, rank):
-    """Contiguous equal blocks; n_total must divide evenly (all-gather needs equal shards)."""
+    """Contiguous equal blocks; n_total must divide evenly (weak scaling: fixed work per GPU)."""
     if n_total % world:
         raise ValueError("n_total (%d) must be a multiple of world size (%d)" % (n_total, world))
     count = n_total // world
     return rank * count, count
 
 
+def owner_of(k, n_total, world):
+    return k // (n_total // world)
+
+
 def plan(n_total, world, rank, n_nbr, neighbours_fn):
-    """Returns dict(first, count, own=[...], nbrs=[[...]], inputs=sorted slots whose IMAGES this
-    rank must hold = own block + its neighbours (the input halo))."""
+    """Returns dict(first, count, own, nbrs, inputs, boundary, interior, recv, send).
+
+    inputs   slots whose IMAGES this rank must hold = own block + its neighbours (input halo)
+    boundary own keyframes some OTHER rank's K4 reads (reconstruct these first, then exchange)
+    interior the rest of the own block
+    recv     {peer: sorted keyframes owned by peer that this rank's K4 reads}
+    send     {peer: sorted own keyframes that peer's K4 reads}
+    Every rank derives every other rank's needs from the same deterministic neighbour function, so
+    send/recv lists match pairwise without negotiation."""
     first, count = block_partition(n_total, world, rank)
     own = list(range(first, first + count))
     nbrs = [list(neighbours_fn(k, n_total, n_nbr)) for k in own]
     need = set(own)
     for row in nbrs:
         need.update(row)
-    return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=sorted(need))
+    recv, send = {}, {}
+    for j in sorted(need):
+        q = owner_of(j, n_total, world)
+        if q != rank:
+            recv.setdefault(q, []).append(j)
+    for q in range(world):
+        if q == rank:
+            continue
+        qf, qc = block_partition(n_total, world, q)
+        wanted = set()
+        for k in range(qf, qf + qc):
+            for j in neighbours_fn(k, n_total, n_nbr):
+                if first <= j < first + count:
+                    wanted.add(j)
+        if wanted:
+            send[q] = sorted(wanted)
+    boundary = sorted({j for lst in send.values() for j in lst})
+    bset = set(boundary)
+    interior = [k for k in own if k not in bset]
+    return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=sorted(need), boundary=boundary,
+                interior=interior, recv=recv, send=send)
+
+
+def _runs(idx):
+    """sorted index list -> list of (start, stop) contiguous runs"""
+    runs = []
+    for i in idx:
+        if runs and runs[-1][1] == i:
+            runs[-1][1] = i + 1
+        else:
+            runs.append([i, i + 1])
+    return [tuple(r) for r in runs]
+
+
+def exchange_halo_async(pool, pl, group=None):
+    """Starts the point-to-point exchange of the boundary maps; returns a list of work handles
+    (empty if there is nothing to exchange).  Contiguous runs of keyframes are sent/received as
+    views of `pool` (zero copy).  Call wait_all() before K4."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return []
+    ops = []
+    for peer in sorted(set(pl["send"]) | set(pl["recv"])):
+        for a, b in _runs(pl["send"].get(peer, [])):
+            ops.append(dist.P2POp(dist.isend, pool[a:b], peer, group=group))
+        for a, b in _runs(pl["recv"].get(peer, [])):
+            ops.append(dist.P2POp(dist.irecv, pool[a:b], peer, group=group))
+    if not ops:
+        return []
+    return dist.batch_isend_irecv(ops)
+
+
+def wait_all(works):
+    for w in works:
+        w.wait()
 
 
 def allgather_depth(pool, first, count, group=None):
-    """In-place all-gather of the depth pool: `pool` is the [n_total, H, W, 2] float32 tensor that
-    backs the engine's depth pool (sdm_config.ext_depth_pool); this rank has just written rows
-    [first, first+count).  After the call every rank holds every keyframe's {rho, sigma}."""
+    """In-place all-gather of the depth pool: this rank has just written rows [first, first+count).
+    After the call every rank holds every keyframe's {rho, sigma}."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     mine = pool[first:first + count]

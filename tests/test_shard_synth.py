@@ -69,21 +69,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, H, W, out):
+def _worker(rank, world, port, n_total, H, W, out, mode="allgather", n_nbr=4):
     sys.path.insert(0, ROOT)
     import sdm_pkg
     pkg = sdm_pkg.load()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    pl = pkg.shard.plan(n_total, world, rank, 4, pkg.synth.Scene.neighbours)
+    pl = pkg.shard.plan(n_total, world, rank, n_nbr, pkg.synth.Scene.neighbours)
     pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32)
     # stand-in for K1-K3: this rank fills only its own block with a recognisable pattern
     for k in pl["own"]:
         pool[k, :, :, 0] = k + 0.25
         pool[k, :, :, 1] = -(k + 0.5)
-    pkg.shard.allgather_depth(pool, pl["first"], pl["count"])
+    if mode == "allgather":
+        pkg.shard.allgather_depth(pool, pl["first"], pl["count"])
+        expect = range(n_total)
+    else:
+        pkg.shard.wait_all(pkg.shard.exchange_halo_async(pool, pl))
+        expect = pl["inputs"]
     ok = True
     for k in range(n_total):
-        ok = ok and bool((pool[k, :, :, 0] == k + 0.25).all()) and bool((pool[k, :, :, 1] == -(k + 0.5)).all())
+        if k in expect:
+            ok = ok and bool((pool[k, :, :, 0] == k + 0.25).all()) and bool((pool[k, :, :, 1] == -(k + 0.5)).all())
+        else:
+            ok = ok and not bool(pool[k].any())  # halo mode moves nothing it does not need
     # every neighbour a rank's K4 will read is now present
     for row in pl["nbrs"]:
         for j in row:
@@ -92,18 +100,49 @@ def _worker(rank, world, port, n_total, H, W, out):
     dist.destroy_process_group()
 
 
-def test_allgather_exchange_gloo_world2(pkg):
-    """the one exchange step of the path (all-gather of per-keyframe {rho,sigma} maps between K3 and
-    K4), world_size 2 on the gloo backend"""
-    world, n_total = 2, 12
+def _run_world(world, n_total, mode, n_nbr=4):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, 6, 8, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, 6, 8, out, mode, n_nbr)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert dict(out) == {0: True, 1: True}
+    assert dict(out) == {r: True for r in range(world)}
+
+
+def test_halo_plan_is_pairwise_consistent(pkg):
+    shard, nb = pkg.shard, pkg.synth.Scene.neighbours
+    for (n_total, world, n) in [(32, 4, 6), (64, 8, 20), (24, 2, 7), (512, 8, 20)]:
+        plans = [shard.plan(n_total, world, r, n, nb) for r in range(world)]
+        for r, pl in enumerate(plans):
+            assert sorted(pl["boundary"] + pl["interior"]) == pl["own"]
+            for q, lst in pl["recv"].items():
+                assert plans[q]["send"][r] == lst, "what r receives from q is what q sends to r"
+            for q, lst in pl["send"].items():
+                assert plans[q]["recv"][r] == lst
+            got = set(pl["own"]) | {j for lst in pl["recv"].values() for j in lst}
+            assert got == set(pl["inputs"])
+        # index-local covisibility: only adjacent blocks talk, N/2 keyframes each way
+        mid = plans[world // 2] if (world > 2 and n_total // world >= n // 2) else None
+        if mid is not None:
+            assert set(mid["recv"]) == {world // 2 - 1, world // 2 + 1}
+            assert all(len(v) == n // 2 for v in mid["recv"].values())
+
+
+def test_halo_exchange_gloo_world2(pkg):
+    """the point-to-point halo exchange between K3 and K4, world_size 2 on gloo"""
+    _run_world(2, 12, "halo")
+
+
+def test_halo_exchange_gloo_world3(pkg):
+    """a middle rank exchanges with both neighbours at once (batched isend/irecv)"""
+    _run_world(3, 24, "halo", n_nbr=6)
+
+
+def test_allgather_exchange_gloo_world2(pkg):
+    """the all-gather form of the exchange (whole depth pool, in place), world_size 2 on gloo"""
+    _run_world(2, 12, "allgather")
