@@ -270,13 +270,16 @@ __device__ __forceinline__ float match_cost(float pe2, float ge2, const DevParam
     double s = (double)pe2 + (double)ge2 * prm.inv_theta;
     unsigned lo = (unsigned)__double2loint(s);
     bool risky = (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) | !(s > 1.0e-30) | !(s < 1.0e30);
-    if (risky) s = (double)pe2 + div_theta((double)ge2, prm.theta_var, prm.inv_theta, prm.fast_theta_div);
+    if (__builtin_expect(risky, 0)) s = (double)pe2 + (double)ge2 / prm.theta_var;
     return (float)s;
 }
 
 // (scan tuning macros)
 #ifndef SDM_BRANCHFREE_GATES
 #define SDM_BRANCHFREE_GATES 0
+#endif
+#ifndef SDM_ABLATE
+#define SDM_ABLATE 0
 #endif
 #ifndef SDM_SCAN_UNROLL
 #define SDM_SCAN_UNROLL 4
@@ -363,6 +366,11 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     // at a time so that four independent 16-byte gathers are in flight per lane.  Fetch addresses
     // are clamped into the image (32-bit byte offsets from a scalar base); validity is decided
     // separately from the unclamped values.
+#if SDM_ABLATE == 6
+    hi = lo - 1;
+    old_err = ab;
+    best_pixel = lo + 2;
+#endif
     for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
         float4 rs[SCAN_UNROLL];
@@ -372,10 +380,19 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
             float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim2);
             int uc = min(uj, hi);
-            unsigned off = (unsigned)((int)yc * W + uc) << 4;
+            unsigned off = (__umul24((unsigned)(int)yc, (unsigned)W) + (unsigned)uc) << 4;  // rows, W < 2^24
             yfs[k] = yf;
+#if SDM_ABLATE == 5
+            rs[k] = make_float4(20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u));
+#else
             rs[k] = *reinterpret_cast<const float4*>(nbase + off);
+#endif
         }
+        // keep each record one 16-byte gather issued here: without this hipcc splits the first record
+        // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++)
+            asm volatile("" : "+v"(rs[k].x), "+v"(rs[k].y), "+v"(rs[k].z), "+v"(rs[k].w));
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             const int uj = u0 + k;
@@ -384,15 +401,21 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             const float4 r = rs[k];
             if (!((uj <= hi) & (yf >= 1.0f) & (yf < hlim))) continue;  // PM.cc:408 + N3
             if (r.x < prm.lambdaG) continue;                            // PM.cc:411
+#if SDM_ABLATE == 4
+            if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
+            continue;
+#endif
             const float d2 = r.y - th_line;     // PM.cc:415-416
             const float d3 = r.y - ang_pi_rot;  // PM.cc:427
-            bool fail;
-            if (prm.default_gates && (d2 < 360.0f) & (d3 < 360.0f))
-                fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
-            else
+            bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+            if (__builtin_expect(!(prm.default_gates && (d2 < 360.0f) & (d3 < 360.0f)), 0))
                 fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
             if (fail) continue;  // PM.cc:421,431
             if (STATS) st->gate_pass++;
+#if SDM_ABLATE == 3 || SDM_ABLATE == 4
+            if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
+            continue;
+#endif
             const int vj = (int)yf;
             float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
             float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
@@ -406,6 +429,11 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         }
     }
     if (!(old_err < 1000000.0f)) return false;  // PM.cc:446
+#if SDM_ABLATE == 2
+    rho_o = old_err + best_pe + (float)best_pixel;
+    sigma_o = best_ge + 1.0f;
+    return true;
+#endif
 
     int up = best_pixel + 1, um = best_pixel - 1;  // PM.cc:449-450
     if (um < 0 || up > W - 1) return false;
@@ -415,8 +443,8 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     if (!(fyp >= 0.0f && fyp <= hlim2)) return false;
     if (!(fym >= 0.0f && fym <= hlim2)) return false;
     int y0p = (int)fyp, y0m = (int)fym;
-    float4 rp = *reinterpret_cast<const float4*>(nbase + ((unsigned)(y0p * W + up) << 4));
-    float4 rm = *reinterpret_cast<const float4*>(nbase + ((unsigned)(y0m * W + um) << 4));
+    float4 rp = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0p, (unsigned)W) + (unsigned)up) << 4));
+    float4 rm = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0m, (unsigned)W) + (unsigned)um) << 4));
     float g = (rec_lerp_im(rp, y0p, yfp) - rec_lerp_im(rm, y0m, yfm)) / 2;      // PM.cc:452
     float q = (rec_lerp_grad(rp, y0p, yfp) - rec_lerp_grad(rm, y0m, yfm)) / 2;  // PM.cc:453
     const double inv_theta = prm.inv_theta;

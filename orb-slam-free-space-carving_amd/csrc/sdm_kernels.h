@@ -273,13 +273,13 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 // footprint at n*64 hypotheses (10 KB at n = 20), which lets 8 waves per SIMD stay resident to
 // hide the gather latency; interleaving j (not blocking it) balances the waves, because the scan
 // length grows with the baseline and neighbours are ordered by covisibility.
-// LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), then the
-// per-(pixel, wave) partial results of the compatibility search.
+// LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), their
+// reciprocal variances, and the per-hypothesis compatible-set sizes: 16 B x n x 64 (20 KB at n = 20).
 constexpr int K1_PX = 64;     // active pixels per workgroup
 constexpr int K1_WAVES = 4;   // neighbour stripes
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
-    return sizeof(float2) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1) + (sizeof(unsigned) + sizeof(unsigned long long)) * BLOCK;
+    return (sizeof(float2) + sizeof(float) + sizeof(unsigned)) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1);
 }
 
 template <bool STATS>
@@ -291,9 +291,9 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
                                                        unsigned long long* __restrict__ stats)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    float2* hyp = reinterpret_cast<float2*>(smem_raw);
-    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(hyp + (size_t)n * K1_PX);
-    unsigned* pkey = reinterpret_cast<unsigned*>(pmask + BLOCK);
+    float2* hyp = reinterpret_cast<float2*>(smem_raw);                // [n][64] {rho, sigma}
+    float* rinv = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] 1/sigma^2 (NaN = take the exact path)
+    unsigned* cnt = reinterpret_cast<unsigned*>(rinv + (size_t)n * K1_PX);  // [n][64] compatible-set sizes
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -338,57 +338,82 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
             if (ok && (1.0f / rho) > 0.0f) h = make_float2(rho, sigma);  // PM.cc:216
         }
         hyp[j * K1_PX + p] = h;
+        rinv[j * K1_PX + p] = safe_rcp_sq(h.y);
+        cnt[j * K1_PX + p] = 0u;
     }
     __syncthreads();
 
-    // InverseDepthHypothesisFusion, PM.cc:598-626: wave w evaluates the compatibility rows
-    // a = w, w+4, ...; the winner is the largest set, ties to the smallest a (PM.cc:616 strict '>').
+    // InverseDepthHypothesisFusion, PM.cc:598-626.  ChiTest is symmetric bit for bit (the squared
+    // difference and the float sum of the two quotients commute), so every unordered pair {a,b} is
+    // tested once and credited to both rows' set sizes (LDS counters).  Rows are dealt to the four
+    // waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.  Wave 0
+    // then takes the first row with the largest count (PM.cc:616: strict '>') and re-derives only
+    // that row's membership for the fusion sum.
     unsigned long long vm = 0;
     for (int bb = 0; bb < n; bb++) {
         float r0 = hyp[bb * K1_PX + p].x;
         if (r0 == r0) vm |= 1ull << bb;
     }
+#if SDM_ABLATE == 1
+    const int nh = 0;
+    if (vm == 0x123456789ull) pool[0] = make_float2(1.f, 1.f);
+#else
     const int nh = __popcll(vm);
-    unsigned bestkey = 0;
-    unsigned long long bestmask = 0;
+#endif
+#if SDM_ABLATE == 9
+    if (nh > prm.lambdaN && w == 0) {
+        for (int a = 0; a < n; a++) atomicAdd(&cnt[a * K1_PX + p], (unsigned)(n - a));
+    }
+    if (false) {
+#else
     if (nh > prm.lambdaN) {  // PM.cc:221
-        for (int a = w; a < n; a += K1_WAVES) {
-            if (!((vm >> a) & 1ull)) continue;
+#endif
+        for (int i = 0; 4 * i < n; i++) {
+            const int a = 4 * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
+            if (a >= n || !((vm >> a) & 1ull)) continue;
             const float2 ha = hyp[a * K1_PX + p];
-            const float ra = safe_rcp_sq(ha.y);
-            unsigned long long m = 0;
-            for (int bb = 0; bb < n; bb++) {
+            const float ra = rinv[a * K1_PX + p];
+            unsigned c = chi_test(ha.x, ha.x, ha.y, ha.y) ? 1u : 0u;  // the self pair (0/0 = NaN for sigma 0)
+            for (int bb = a + 1; bb < n; bb++) {
                 if (!((vm >> bb) & 1ull)) continue;
                 const float2 hb = hyp[bb * K1_PX + p];
-                if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, safe_rcp_sq(hb.y))) m |= 1ull << bb;
+                if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p])) {
+                    c++;
+                    atomicAdd(&cnt[bb * K1_PX + p], 1u);
+                }
             }
-            const unsigned key = ((unsigned)__popcll(m) << 6) | (unsigned)(63 - a);
-            if (key > bestkey) {
-                bestkey = key;
-                bestmask = m;
-            }
+            atomicAdd(&cnt[a * K1_PX + p], c);
         }
     }
-    pkey[tid] = bestkey;
-    pmask[tid] = bestmask;
     __syncthreads();
 
     unsigned long long n_fused = 0;
     if (w == 0 && on && nh > prm.lambdaN) {
-#pragma unroll
-        for (int q = 1; q < K1_WAVES; q++) {
-            const unsigned k2 = pkey[q * K1_PX + p];
-            if (k2 > bestkey) {
-                bestkey = k2;
-                bestmask = pmask[q * K1_PX + p];
+        unsigned best = 0;
+        int besta = 0;
+        for (int a = 0; a < n; a++) {
+            if (!((vm >> a) & 1ull)) continue;
+            const unsigned c = cnt[a * K1_PX + p];
+            if (c > best) {  // first largest set wins
+                best = c;
+                besta = a;
             }
         }
-        if ((int)(bestkey >> 6) >= prm.lambdaN) {  // PM.cc:623
-            float pjsj = 0.f, rsj = 0.f;          // GetFusion overload B, PM.cc:947-970
+        if ((int)best >= prm.lambdaN) {  // PM.cc:623
+            const float2 ha = hyp[besta * K1_PX + p];
+            const float ra = rinv[besta * K1_PX + p];
+            float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
+#if SDM_ABLATE == 8
+            pjsj = ha.x; rsj = ra;
+            for (int bb = 0; bb < 0; bb++) {
+#else
             for (int bb = 0; bb < n; bb++) {
-                if (!((bestmask >> bb) & 1ull)) continue;
+#endif
+                if (!((vm >> bb) & 1ull)) continue;
                 const float2 hb = hyp[bb * K1_PX + p];
-                fusion_accum(hb.x, hb.y, pjsj, rsj);
+                const bool in = (bb == besta) ? chi_test(ha.x, ha.x, ha.y, ha.y)
+                                              : chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p]);
+                if (in) fusion_accum(hb.x, hb.y, pjsj, rsj);
             }
             pool[(long long)rc.slot * plane + y * W + x] = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
             n_fused = 1;
