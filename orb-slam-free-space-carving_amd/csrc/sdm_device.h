@@ -477,12 +477,34 @@ __device__ __forceinline__ bool chi_test(float a, float b, float sa, float sb)
     return (double)chi < 5.99;
 }
 
-// one term of GetFusion (PM.cc:936-937 / 956-957): pow(sigma,2) is double, the sums are float
-__device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, float& rsj)
+// one term of GetFusion (PM.cc:936-937 / 956-957): pow(sigma,2) is double, the sums are float.
+// The two double quotients rho/s2 and 1/s2 share their divisor: r = 1/s2 is a true (correctly
+// rounded) division and rho/s2 is recovered from it with two FMA residual corrections
+// (Markstein: with r = RN(1/b) and q within an ulp of a/b, fma(fma(-q,b,a), r, q) = RN(a/b); b = s2
+// is the exact square of a float, so its significand is never all ones).  Operands outside the
+// comfortable range take the plain division.  sdm_selftest(4) compares the two forms.
+__device__ __forceinline__ double div_by_with_rcp(double a, double b, double r)
+{
+    double q0 = a * r;
+    double e0 = __builtin_fma(-q0, b, a);
+    double q1 = __builtin_fma(e0, r, q0);
+    double e1 = __builtin_fma(-q1, b, a);
+    return __builtin_fma(e1, r, q1);
+}
+__device__ __forceinline__ void fusion_terms(float rho, float sg, double& t_rho, double& t_one)
 {
     double s2 = (double)sg * (double)sg;
-    pjsj = (float)((double)pjsj + (double)rho / s2);
-    rsj = (float)((double)rsj + 1.0 / s2);
+    t_one = 1.0 / s2;
+    const float ar = fabsf(rho);
+    const bool safe = (s2 > 1.0e-60) & (s2 < 1.0e60) & (ar > 1.0e-30f) & (ar < 1.0e30f);
+    t_rho = safe ? div_by_with_rcp((double)rho, s2, t_one) : (double)rho / s2;
+}
+__device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, float& rsj)
+{
+    double t_rho, t_one;
+    fusion_terms(rho, sg, t_rho, t_one);
+    pjsj = (float)((double)pjsj + t_rho);
+    rsj = (float)((double)rsj + t_one);
 }
 
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.

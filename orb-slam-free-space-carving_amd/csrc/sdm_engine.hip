@@ -61,6 +61,7 @@ struct sdm_ctx {
     std::vector<char> has_depth, has_chk;
     unsigned* d_act = nullptr;     // [max_keyframes][P] active-pixel lists (y<<16|x), raster order
     int* d_act_count = nullptr;    // [max_keyframes]
+    int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     std::vector<int> h_act_count;  // host mirror
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
@@ -120,8 +121,14 @@ void set_dev_params(sdm_ctx* c)
 // (re)build the active-pixel list of a slot for the current lambdaG; reads the count back
 int build_active(sdm_ctx* c, int slot)
 {
-    hipLaunchKernelGGL(k_build_active, dim3(1), dim3(ACT_BLOCK), 0, c->stream, c->rec + (long long)slot * c->P, c->W,
-                       c->H, c->dprm.lambdaG, c->d_act + (long long)slot * c->P, c->d_act_count + slot);
+    const int n_chunks = (int)((c->P + ACT_BLOCK - 1) / ACT_BLOCK);
+    const float4* r = c->rec + (long long)slot * c->P;
+    hipLaunchKernelGGL(k_active_count, dim3(n_chunks), dim3(ACT_BLOCK), 0, c->stream, r, c->W, c->H, c->dprm.lambdaG,
+                       c->d_chunk);
+    hipLaunchKernelGGL(k_active_scan, dim3(1), dim3(ACT_BLOCK), 0, c->stream, c->d_chunk, n_chunks,
+                       c->d_act_count + slot);
+    hipLaunchKernelGGL(k_active_write, dim3(n_chunks), dim3(ACT_BLOCK), 0, c->stream, r, c->W, c->H, c->dprm.lambdaG,
+                       c->d_chunk, c->d_act + (long long)slot * c->P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&c->h_act_count[slot], c->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost,
                            c->stream));
@@ -271,7 +278,7 @@ int pack_staged(sdm_ctx* c, int slot)
 int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
 {
     HIP_TRY(hipMemsetAsync(c->d_sums, 0, 2 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_gradient, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->W, c->H, c->d_grad,
+    hipLaunchKernelGGL(k_gradient, dim3(c->geom.ntiles), dim3(BLOCK), 0, c->stream, d_image, c->W, c->H, c->d_grad,
                        c->d_theta, c->d_sums);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_istd_finish, dim3(1), dim3(1), 0, c->stream, c->d_sums, c->W, c->H, c->d_meta + slot);
@@ -401,6 +408,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_meta, (size_t)K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_act, (size_t)c->P * K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_act_count, (size_t)K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_chunk, (size_t)((c->P + ACT_BLOCK - 1) / ACT_BLOCK)))) return bail(rc);
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
@@ -454,6 +462,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_act);
     (void)hipFree(c->d_act_count);
+    (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
@@ -1074,6 +1083,9 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
                            c->d_stats + 6);
     } else if (which == 2) {
         hipLaunchKernelGGL(k_selftest_cost, dim3(1024), dim3(BLOCK), 0, c->stream, c->dprm, 2048, c->d_stats + 5,
+                           c->d_stats + 6);
+    } else if (which == 4) {
+        hipLaunchKernelGGL(k_selftest_fusion_terms, dim3(4096), dim3(BLOCK), 0, c->stream, 2048, c->d_stats + 5,
                            c->d_stats + 6);
     } else if (which == 3) {
         hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);

@@ -82,6 +82,9 @@ __device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], uns
     return total;
 }
 
+constexpr int HALO_W_K0 = TILE_W + 2;
+constexpr int HALO_H_K0 = TILE_H + 2;
+
 // ---- K0: input pre-pass ---------------------------------------------------------------------------
 // Scharr/32 gradient, magnitude, fastAtan2 phase (the pre-processing PM.cc assumes on KeyFrame:
 // GradImg / GradTheta) + exact integer sums for I_stddev.
@@ -89,22 +92,35 @@ __global__ __launch_bounds__(BLOCK) void k_gradient(const uint8_t* __restrict__ 
                                                     float* __restrict__ grad, float* __restrict__ theta,
                                                     unsigned long long* __restrict__ sums)
 {
-    int idx = blockIdx.x * BLOCK + threadIdx.x;
+    // one 64x16 tile per workgroup, staged with its replicated 1-px border in LDS
+    __shared__ uint8_t t[HALO_H_K0][HALO_W_K0];
+    const int tiles_x = (W + TILE_W - 1) / TILE_W;
+    const int tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
+    for (int i = threadIdx.x; i < HALO_H_K0 * HALO_W_K0; i += BLOCK) {
+        int hy = i / HALO_W_K0, hx = i - hy * HALO_W_K0;
+        int x = min(max(tx0 + hx - 1, 0), W - 1), y = min(max(ty0 + hy - 1, 0), H - 1);
+        t[hy][hx] = im[y * W + x];
+    }
+    __syncthreads();
     unsigned long long s = 0, sq = 0;
-    if (idx < W * H) {
-        int y = idx / W, x = idx - y * W;
-        int ym = max(y - 1, 0), yp = min(y + 1, H - 1), xm = max(x - 1, 0), xp = min(x + 1, W - 1);
-        int a00 = im[ym * W + xm], a01 = im[ym * W + x], a02 = im[ym * W + xp];
-        int a10 = im[y * W + xm], a11 = im[y * W + x], a12 = im[y * W + xp];
-        int a20 = im[yp * W + xm], a21 = im[yp * W + x], a22 = im[yp * W + xp];
-        int sx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
-        int sy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
-        float gx = (float)sx * (1.0f / 32.0f), gy = (float)sy * (1.0f / 32.0f);
-        float xx = gx * gx, yy = gy * gy;
-        grad[idx] = sqrtf(xx + yy);
-        theta[idx] = fast_atan2_deg(gy, gx);
-        s = (unsigned long long)a11;
-        sq = (unsigned long long)(a11 * a11);
+#pragma unroll
+    for (int i = 0; i < PX_PER_THREAD; i++) {
+        int L = i * BLOCK + threadIdx.x;
+        int lx = L & (TILE_W - 1), ly = L >> 6;
+        int x = tx0 + lx, y = ty0 + ly;
+        if (x < W && y < H) {
+            int a00 = t[ly][lx], a01 = t[ly][lx + 1], a02 = t[ly][lx + 2];
+            int a10 = t[ly + 1][lx], a11 = t[ly + 1][lx + 1], a12 = t[ly + 1][lx + 2];
+            int a20 = t[ly + 2][lx], a21 = t[ly + 2][lx + 1], a22 = t[ly + 2][lx + 2];
+            int sx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
+            int sy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
+            float gx = (float)sx * (1.0f / 32.0f), gy = (float)sy * (1.0f / 32.0f);
+            float xx = gx * gx, yy = gy * gy;
+            grad[y * W + x] = sqrtf(xx + yy);
+            theta[y * W + x] = fast_atan2_deg(gy, gx);
+            s += (unsigned long long)a11;
+            sq += (unsigned long long)(a11 * a11);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o);
@@ -218,40 +234,80 @@ __global__ void k_ref_setup(const KfMeta* __restrict__ meta, const int* __restri
 // so it is built ONCE when the keyframe is uploaded: act[] holds (y << 16 | x) of the inset pixels
 // that pass the gate, in raster order (one workgroup per keyframe, deterministic).
 constexpr int ACT_BLOCK = 1024;
-__global__ __launch_bounds__(ACT_BLOCK) void k_build_active(const float4* __restrict__ rec, int W, int H,
-                                                            float lambdaG, unsigned* __restrict__ act,
-                                                            int* __restrict__ count)
+__device__ __forceinline__ bool act_flag(const float4* __restrict__ rec, int W, int H, float lambdaG, int idx,
+                                         int& x, int& y)
+{
+    if (idx >= W * H) return false;
+    y = idx / W;
+    x = idx - y * W;
+    if (!(x >= 2 && x < W - 2 && y >= 2 && y < H - 2)) return false;  // PM.cc:198-199
+    return !(rec[idx].x < lambdaG);                                   // PM.cc:201
+}
+// pass 1: active pixels per 1024-pixel chunk
+__global__ __launch_bounds__(ACT_BLOCK) void k_active_count(const float4* __restrict__ rec, int W, int H,
+                                                            float lambdaG, int* __restrict__ chunk_count)
 {
     __shared__ int wsum[ACT_BLOCK / 64];
-    __shared__ int base_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_s = 0;
+    int x, y;
+    const bool f = act_flag(rec, W, H, lambdaG, blockIdx.x * ACT_BLOCK + threadIdx.x, x, y);
+    unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
-    const int P = W * H;
-    for (int start = 0; start < P; start += ACT_BLOCK) {
-        int idx = start + tid;
-        bool f = false;
-        int x = 0, y = 0;
-        if (idx < P) {
-            y = idx / W;
-            x = idx - y * W;
-            if (x >= 2 && x < W - 2 && y >= 2 && y < H - 2) f = !(rec[idx].x < lambdaG);  // PM.cc:198-201
-        }
-        unsigned long long m = __ballot(f);
-        if (lane == 0) wsum[wave] = __popcll(m);
-        __syncthreads();
-        int off = base_s;
-        for (int w = 0; w < wave; w++) off += wsum[w];
-        if (f) act[off + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)y << 16) | (unsigned)x;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < ACT_BLOCK / 64; w++) tot += wsum[w];
-            base_s += tot;
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < ACT_BLOCK / 64; w++) tot += wsum[w];
+        chunk_count[blockIdx.x] = tot;
     }
-    if (tid == 0) *count = base_s;
+}
+// pass 2: exclusive scan of the chunk counts (one workgroup; <= 2^20 chunks is far beyond any image)
+__global__ __launch_bounds__(ACT_BLOCK) void k_active_scan(int* __restrict__ chunk_count, int n_chunks,
+                                                           int* __restrict__ total)
+{
+    __shared__ int part[ACT_BLOCK];
+    const int tid = threadIdx.x;
+    const int per = (n_chunks + ACT_BLOCK - 1) / ACT_BLOCK;
+    int s = 0;
+    for (int i = 0; i < per; i++) {
+        int k = tid * per + i;
+        if (k < n_chunks) s += chunk_count[k];
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < ACT_BLOCK; i++) {
+            int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = 0; i < per; i++) {
+        int k = tid * per + i;
+        if (k < n_chunks) {
+            int v = chunk_count[k];
+            chunk_count[k] = run;
+            run += v;
+        }
+    }
+}
+// pass 3: write the list in raster order
+__global__ __launch_bounds__(ACT_BLOCK) void k_active_write(const float4* __restrict__ rec, int W, int H,
+                                                            float lambdaG, const int* __restrict__ chunk_off,
+                                                            unsigned* __restrict__ act)
+{
+    __shared__ int wsum[ACT_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x = 0, y = 0;
+    const bool f = act_flag(rec, W, H, lambdaG, blockIdx.x * ACT_BLOCK + tid, x, y);
+    unsigned long long m = __ballot(f);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = chunk_off[blockIdx.x];
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (f) act[off + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)y << 16) | (unsigned)x;
 }
 
 // zero the depth maps of a batch's reference keyframes (a fresh depth_map_/depth_sigma_)
@@ -279,7 +335,8 @@ constexpr int K1_PX = 64;     // active pixels per workgroup
 constexpr int K1_WAVES = 4;   // neighbour stripes
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
-    return (sizeof(float2) + sizeof(float) + sizeof(unsigned)) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1);
+    return (sizeof(float2) + sizeof(float) + sizeof(unsigned)) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1) +
+           sizeof(unsigned long long) * BLOCK;
 }
 
 template <bool STATS>
@@ -294,6 +351,7 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     float2* hyp = reinterpret_cast<float2*>(smem_raw);                // [n][64] {rho, sigma}
     float* rinv = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] 1/sigma^2 (NaN = take the exact path)
     unsigned* cnt = reinterpret_cast<unsigned*>(rinv + (size_t)n * K1_PX);  // [n][64] compatible-set sizes
+    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)n * K1_PX);  // [4][64]
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -327,20 +385,29 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     }
     SearchStats st = {0, 0, 0};
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
+    // Hypotheses go to LDS in neighbour order.  "No hypothesis" (PM.cc:216) is stored as rho = +Inf,
+    // sigma = 1: against any real hypothesis the squared difference is +Inf, so the compatibility
+    // test fails on its fast path and the pair loops need no validity checks.  Each wave also keeps
+    // the validity bits of its own neighbours; the four partial masks are OR-ed after the barrier.
+    unsigned long long mymask = 0;
     for (int j = w; j < n; j += K1_WAVES) {
         const PairConst* __restrict__ pc = pcs + j;
         const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
-        float2 h = make_float2(__builtin_nanf(""), 0.f);
+        float2 h = make_float2(__builtin_inff(), 1.0f);
         if (on) {
             float rho, sigma, bu, bv;
             bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0, xp1,
                                              rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
-            if (ok && (1.0f / rho) > 0.0f) h = make_float2(rho, sigma);  // PM.cc:216
+            if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
+                h = make_float2(rho, sigma);
+                mymask |= 1ull << j;
+            }
         }
         hyp[j * K1_PX + p] = h;
         rinv[j * K1_PX + p] = safe_rcp_sq(h.y);
         cnt[j * K1_PX + p] = 0u;
     }
+    pmask[tid] = mymask;
     __syncthreads();
 
     // InverseDepthHypothesisFusion, PM.cc:598-626.  ChiTest is symmetric bit for bit (the squared
@@ -349,33 +416,22 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     // waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.  Wave 0
     // then takes the first row with the largest count (PM.cc:616: strict '>') and re-derives only
     // that row's membership for the fusion sum.
-    unsigned long long vm = 0;
-    for (int bb = 0; bb < n; bb++) {
-        float r0 = hyp[bb * K1_PX + p].x;
-        if (r0 == r0) vm |= 1ull << bb;
-    }
+    const unsigned long long vm = pmask[p] | pmask[K1_PX + p] | pmask[2 * K1_PX + p] | pmask[3 * K1_PX + p];
 #if SDM_ABLATE == 1
     const int nh = 0;
     if (vm == 0x123456789ull) pool[0] = make_float2(1.f, 1.f);
 #else
     const int nh = __popcll(vm);
 #endif
-#if SDM_ABLATE == 9
-    if (nh > prm.lambdaN && w == 0) {
-        for (int a = 0; a < n; a++) atomicAdd(&cnt[a * K1_PX + p], (unsigned)(n - a));
-    }
-    if (false) {
-#else
     if (nh > prm.lambdaN) {  // PM.cc:221
-#endif
         for (int i = 0; 4 * i < n; i++) {
             const int a = 4 * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
             if (a >= n || !((vm >> a) & 1ull)) continue;
             const float2 ha = hyp[a * K1_PX + p];
             const float ra = rinv[a * K1_PX + p];
-            unsigned c = chi_test(ha.x, ha.x, ha.y, ha.y) ? 1u : 0u;  // the self pair (0/0 = NaN for sigma 0)
+            // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
+            unsigned c = (ha.y * ha.y > 0.0f) ? 1u : 0u;
             for (int bb = a + 1; bb < n; bb++) {
-                if (!((vm >> bb) & 1ull)) continue;
                 const float2 hb = hyp[bb * K1_PX + p];
                 if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p])) {
                     c++;
@@ -411,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
 #endif
                 if (!((vm >> bb) & 1ull)) continue;
                 const float2 hb = hyp[bb * K1_PX + p];
-                const bool in = (bb == besta) ? chi_test(ha.x, ha.x, ha.y, ha.y)
+                const bool in = (bb == besta) ? (ha.y * ha.y > 0.0f)
                                               : chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p]);
                 if (in) fusion_accum(hb.x, hb.y, pjsj, rsj);
             }
@@ -1011,6 +1067,40 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_cost(DevParams prm, int iter
     if ((threadIdx.x & 63) == 0) {
         if (cnt) atomicAdd(bad, cnt);
         if (hits) atomicAdd(risky_hits, hits);
+    }
+}
+
+// which = 4: the shared-reciprocal form of GetFusion's two double quotients vs two plain divisions,
+// over random (rho, sigma) across many magnitudes and the special values.
+__global__ __launch_bounds__(BLOCK) void k_selftest_fusion_terms(int iters, unsigned long long* __restrict__ bad,
+                                                                 unsigned long long* __restrict__ tested)
+{
+    unsigned s = 0x27D4EB2Fu * (blockIdx.x * BLOCK + threadIdx.x + 1);
+    unsigned long long cnt = 0, n = 0;
+    const float specials[8] = {0.f, 1e-41f, 1e-25f, 1e25f, __builtin_inff(), __builtin_nanf(""), -1.0f, 3e38f};
+    for (int i = 0; i < iters; i++) {
+        // random bit patterns restricted to exponents in a wide band, so every mantissa occurs
+        unsigned br = xs32(s), bs = xs32(s);
+        float rho = __uint_as_float((br & 0x807FFFFFu) | ((100u + (br >> 23) % 56u) << 23));
+        float sg = __uint_as_float((bs & 0x007FFFFFu) | ((100u + (bs >> 23) % 56u) << 23));
+        unsigned pick = xs32(s);
+        if ((pick & 255u) == 0) rho = specials[(pick >> 8) & 7];
+        if ((pick & 255u) == 1) sg = specials[(pick >> 8) & 7];
+        double t_rho, t_one;
+        fusion_terms(rho, sg, t_rho, t_one);
+        double s2 = (double)sg * (double)sg;
+        double e_rho = (double)rho / s2, e_one = 1.0 / s2;
+        if (!(t_rho == e_rho || (t_rho != t_rho && e_rho != e_rho))) cnt++;
+        if (!(t_one == e_one || (t_one != t_one && e_one != e_one))) cnt++;
+        n++;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        n += __shfl_down(n, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        atomicAdd(tested, n);
     }
 }
 

@@ -38,3 +38,12 @@ def test_angle_gates_closed_form(pkg, gpu_ok):
     assert bad == 0
     assert tested > 2 ** 31
     eng.close()
+
+
+def test_fusion_terms_shared_reciprocal(pkg, gpu_ok):
+    """GetFusion's rho/sigma^2 via the reciprocal 1/sigma^2 + FMA corrections == the plain double division"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, tested = eng.selftest(4)
+    assert bad == 0
+    assert tested >= 2 ** 31
+    eng.close()
