@@ -507,6 +507,32 @@ __device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, f
     rsj = (float)((double)rsj + t_one);
 }
 
+// ---- float quotients that share a divisor -------------------------------------------------------------------
+// a/b from r = 1.0f/b (a true, correctly rounded division done once) with two FMA residual
+// corrections (Markstein): bit-identical to the IEEE quotient provided b's significand is not all
+// ones and nothing leaves the normal range -- quot_ok_* check exactly that; otherwise the caller
+// divides.  sdm_selftest(5) compares both forms over 2^33 operand pairs.
+__device__ __forceinline__ bool quot_ok_divisor(float b)
+{
+    unsigned u = __float_as_uint(b);
+    unsigned e = (u >> 23) & 0xffu;
+    return (e >= 64u) & (e <= 190u) & ((u & 0x7FFFFFu) != 0x7FFFFFu);  // |b| in [2^-63, 2^63]
+}
+__device__ __forceinline__ bool quot_ok_numerator(float a)
+{
+    unsigned e = (__float_as_uint(a) >> 23) & 0xffu;
+    return ((e >= 87u) & (e <= 167u)) | (a == 0.0f);  // 0 or |a| in [2^-40, 2^40]
+}
+__device__ __forceinline__ float quot_with_rcp(float a, float b, float r, bool b_ok)
+{
+    if (__builtin_expect(!(b_ok && quot_ok_numerator(a)), 0)) return a / b;
+    float q0 = a * r;
+    float e0 = __builtin_fmaf(-q0, b, a);
+    float q1 = __builtin_fmaf(e0, r, q0);
+    float e1 = __builtin_fmaf(-q1, b, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.
 //
 // The N^2 ChiTest divisions dominate a naive port.  Each decision "chi < 5.99" is first tried with

@@ -56,6 +56,7 @@ struct sdm_ctx {
     float2* scratch = nullptr;
     float* chk = nullptr;
     float* xyz = nullptr;
+
     KfMeta* d_meta = nullptr;
     std::vector<KfMeta> h_meta;
     std::vector<char> has_depth, has_chk;
@@ -403,6 +404,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     }
     if ((rc = dev_alloc(&c->scratch, (size_t)c->P * c->cfg.batch_capacity))) return bail(rc);
     if ((rc = dev_alloc(&c->chk, (size_t)c->P * K))) return bail(rc);
+
     if (cfg->with_pointset)
         if ((rc = dev_alloc(&c->xyz, (size_t)c->P * 3 * K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_meta, (size_t)K))) return bail(rc);
@@ -458,6 +460,7 @@ void sdm_destroy(sdm_ctx* c)
     if (c->own_pool) (void)hipFree(c->pool);
     (void)hipFree(c->scratch);
     (void)hipFree(c->chk);
+
     (void)hipFree(c->xyz);
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_act);
@@ -1086,6 +1089,9 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
                            c->d_stats + 6);
     } else if (which == 4) {
         hipLaunchKernelGGL(k_selftest_fusion_terms, dim3(4096), dim3(BLOCK), 0, c->stream, 2048, c->d_stats + 5,
+                           c->d_stats + 6);
+    } else if (which == 5) {
+        hipLaunchKernelGGL(k_selftest_quot, dim3(4096), dim3(BLOCK), 0, c->stream, 8192, c->d_stats + 5,
                            c->d_stats + 6);
     } else if (which == 3) {
         hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);

@@ -736,34 +736,45 @@ __device__ __forceinline__ bool tap_compatible(float depthj, float d, float sg)
     return (double)test < 3.84;
 }
 
-// One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764).
-__device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool, long long plane,
-                                                   const RefConst& rc, const PairConst* __restrict__ pcs, int n,
-                                                   int W, int H, int x, int y, float depthp, int lambdaN)
+struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizontally adjacent pixels
+    float r0, s0, r1, s1;
+};
+
+// One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764).  Quotients sharing a
+// divisor (the three /depthp, the two /t2, the two /d2sigma) use quot_with_rcp (sdm_device.h).
+__device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
+                                                   long long plane, const RefConst& rc,
+                                                   const PairConst* __restrict__ pcs, int n, int W, int H, int x,
+                                                   int y, float depthp, int lambdaN)
 {
     const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
     const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
     const float dp = 1 / depthp;                                                        // PM.cc:769
+    const bool dp_ok = quot_ok_divisor(depthp);
     int kf_count = 0;
     float sum_Jr = 0.f, sum_JJ = 0.f;
     for (int j = 0; j < n; j++) {
         const PairConst* __restrict__ pc = pcs + j;
         const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
-        float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
-        float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
+        float t0 = quot_with_rcp(row_dot_xp(pc->R + 0, xp0, xp1), depthp, dp, dp_ok) + pc->t[0];  // PM.cc:678
+        float t1 = quot_with_rcp(row_dot_xp(pc->R + 3, xp0, xp1), depthp, dp, dp_ok) + pc->t[1];
         float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-        float t2 = rzxp / depthp + pc->t[2];
+        float t2 = quot_with_rcp(rzxp, depthp, dp, dp_ok) + pc->t[2];
         float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
         float v = pc->nfy * t1 + pc->ncy * t2;
-        float xj = u / t2, yj = v / t2;  // PM.cc:680
+        const float r2 = 1.0f / t2;
+        const bool t2_ok = quot_ok_divisor(t2);
+        float xj = quot_with_rcp(u, t2, r2, t2_ok), yj = quot_with_rcp(v, t2, r2, t2_ok);  // PM.cc:680
         float denom2 = depthp * pc->t[2];
         float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
         if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) continue;  // PM.cc:695
         int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
         // four taps fetched together; order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
-        float2 h[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) h[k] = nb[(y0 + (k & 1)) * W + x0 + (k >> 1)];
+        // each image row's two taps are adjacent float2's: one 16-byte (8-byte aligned) load per row
+        const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
+        const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+        const float2 h[4] = {make_float2(ra.r0, ra.s0), make_float2(rb.r0, rb.s0), make_float2(ra.r1, ra.s1),
+                             make_float2(rb.r1, rb.s1)};
         int nj = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -771,8 +782,10 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
                 nj++;
                 float djn = 1 / h[k].x;  // PM.cc:777-783
                 float d2sigma = djn * djn * h[k].y;
-                float J = -rzxp / d2sigma;
-                float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;
+                const float rd = 1.0f / d2sigma;  // J and r0 share the divisor d2sigma
+                const bool d_ok = quot_ok_divisor(d2sigma);
+                float J = quot_with_rcp(-rzxp, d2sigma, rd, d_ok);                          // PM.cc:782
+                float r0 = quot_with_rcp(djn - dp * rzxp - pc->t[2], d2sigma, rd, d_ok);   // PM.cc:783
                 sum_Jr = sum_Jr + J * r0;
                 sum_JJ = sum_JJ + J * J;
             }
@@ -1092,6 +1105,37 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_fusion_terms(int iters, unsi
         double e_rho = (double)rho / s2, e_one = 1.0 / s2;
         if (!(t_rho == e_rho || (t_rho != t_rho && e_rho != e_rho))) cnt++;
         if (!(t_one == e_one || (t_one != t_one && e_one != e_one))) cnt++;
+        n++;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        n += __shfl_down(n, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        atomicAdd(tested, n);
+    }
+}
+
+// which = 5: float quotient from a shared reciprocal (quot_with_rcp) vs the IEEE division.
+__global__ __launch_bounds__(BLOCK) void k_selftest_quot(int iters, unsigned long long* __restrict__ bad,
+                                                         unsigned long long* __restrict__ tested)
+{
+    unsigned s = 0x165667B1u * (blockIdx.x * BLOCK + threadIdx.x + 1);
+    unsigned long long cnt = 0, n = 0;
+    for (int i = 0; i < iters; i++) {
+        unsigned ba = xs32(s), bb = xs32(s);
+        // exponents spread over and beyond the guarded ranges; all mantissas; both signs
+        float a = __uint_as_float((ba & 0x807FFFFFu) | ((70u + (ba >> 23) % 114u) << 23));
+        float b = __uint_as_float((bb & 0x807FFFFFu) | ((50u + (bb >> 23) % 154u) << 23));
+        unsigned pick = xs32(s);
+        if ((pick & 127u) == 0) a = 0.0f;
+        if ((pick & 127u) == 1) b = __uint_as_float(__float_as_uint(b) | 0x7FFFFFu);  // all-ones significand
+        if ((pick & 127u) == 2) a = __uint_as_float(__float_as_uint(b) + ((pick >> 8) & 3u));  // a ~ b
+        float r = 1.0f / b;
+        float q = quot_with_rcp(a, b, r, quot_ok_divisor(b));
+        float e = a / b;
+        if (!(q == e || (q != q && e != e))) cnt++;
         n++;
     }
     for (int o = 32; o > 0; o >>= 1) {

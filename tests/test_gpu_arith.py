@@ -47,3 +47,12 @@ def test_fusion_terms_shared_reciprocal(pkg, gpu_ok):
     assert bad == 0
     assert tested >= 2 ** 31
     eng.close()
+
+
+def test_shared_divisor_quotient(pkg, gpu_ok):
+    """a/b from one reciprocal + two FMA corrections == IEEE division (guards route the rest)"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, tested = eng.selftest(5)
+    assert bad == 0
+    assert tested >= 2 ** 33
+    eng.close()
