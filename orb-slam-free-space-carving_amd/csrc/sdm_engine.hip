@@ -65,6 +65,7 @@ struct sdm_ctx {
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     std::vector<int> h_act_count;  // host mirror
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
+    std::vector<char> chk_sparse, xyz_sparse;  // checked / xyz plane of the slot is zero outside its active list
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
                                        // came from elsewhere, e.g. sdm_upload_depth): K4 may use the list
 
@@ -252,6 +253,8 @@ int reset_slot(sdm_ctx* c, int slot)
     c->has_chk[slot] = 0;
     c->recon_lambdaG[slot] = std::nanf("");
     c->act_lambdaG[slot] = std::nanf("");
+    c->chk_sparse[slot] = 1;
+    c->xyz_sparse[slot] = 1;
     HIP_TRY(hipMemsetAsync(c->pool + (long long)slot * c->P, 0, sizeof(float2) * c->P, c->stream));
     HIP_TRY(hipMemsetAsync(c->chk + (long long)slot * c->P, 0, sizeof(float) * c->P, c->stream));
     if (c->xyz) HIP_TRY(hipMemsetAsync(c->xyz + (long long)slot * c->P * 3, 0, sizeof(float) * 3 * c->P, c->stream));
@@ -380,6 +383,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->h_act_count.assign(K, 0);
     c->act_lambdaG.assign(K, std::nanf(""));
     c->recon_lambdaG.assign(K, std::nanf(""));
+    c->chk_sparse.assign(K, 1);  // planes start zeroed
+    c->xyz_sparse.assign(K, 1);
 
     int rc = SDM_OK;
     auto bail = [&](int code) {
@@ -602,11 +607,17 @@ int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* t
 }
 
 // ---- K1..K3 ----------------------------------------------------------------------------------------------------
+static bool all_pipeline_maps(sdm_ctx* c, int n_ref, const int* ref_slots);
+
 static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots)
 {
-    hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
-                       c->d_ref_slots, n_ref);
-    HIP_TRY(hipGetLastError());
+    // K1 writes every listed pixel; the rest of the map must be zero (a fresh depth_map_).  It already is
+    // when the slot's current map came out of SemiDenseRecon under the same lambdaG.
+    if (!all_pipeline_maps(c, n_ref, ref_slots)) {
+        hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                           c->d_ref_slots, n_ref);
+        HIP_TRY(hipGetLastError());
+    }
     StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);  // brackets exactly one k_search_fuse launch
     int max_chunks = 0;
     for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + K1_PX - 1) / K1_PX);
@@ -804,9 +815,14 @@ int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
             max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
         }
         if (from_recon) {
-            hipLaunchKernelGGL(k_rho_copy, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->chk,
-                               c->P, c->d_ref_slots, n_ref);
-            HIP_TRY(hipGetLastError());
+            bool chk_ok = true;  // checked planes already zero outside the lists?
+            for (int r = 0; r < n_ref; r++) chk_ok = chk_ok && c->chk_sparse[ref_slots[r]];
+            if (!chk_ok) {
+                hipLaunchKernelGGL(k_rho_copy, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
+                                   c->chk, c->P, c->d_ref_slots, n_ref);
+                HIP_TRY(hipGetLastError());
+            }
+            for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 1;
             if (max_chunks > 0) {
                 hipLaunchKernelGGL(k_inter_check_list, dim3(8 * ((max_chunks + 7) / 8) * n_ref), dim3(BLOCK), 0,
                                    c->stream, c->pool, c->P, c->d_refs, c->d_pairs, n_ref, n, c->W, c->H, max_chunks,
@@ -814,6 +830,7 @@ int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
                 HIP_TRY(hipGetLastError());
             }
         } else {
+            for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 0;  // the generic kernel copies arbitrary maps
             hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
                                c->P, c->d_refs, c->d_pairs, n_ref, n, c->geom, c->dprm.lambdaN, c->chk);
             HIP_TRY(hipGetLastError());
@@ -837,8 +854,25 @@ int sdm_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int source)
     const float* src = source ? c->chk : (const float*)c->pool;
     const int sstride = source ? 1 : 2;
     StageTimer tm(c, SDM_STAGE_POINTSET);
-    hipLaunchKernelGGL(k_pointset, dim3(blocks_for(c->P), n_ref), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
-                       c->d_meta, c->d_ref_slots, n_ref, c->W, c->H, c->xyz);
+    // list form when source map and xyz plane are both zero outside the active lists
+    bool sparse = all_pipeline_maps(c, n_ref, ref_slots);
+    int max_chunks = 0;
+    for (int r = 0; r < n_ref; r++) {
+        sparse = sparse && c->xyz_sparse[ref_slots[r]] && (!source || c->chk_sparse[ref_slots[r]]);
+        max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
+    }
+    if (sparse) {
+        if (max_chunks > 0)
+            hipLaunchKernelGGL(k_pointset_list, dim3(8 * ((max_chunks + 7) / 8) * n_ref), dim3(BLOCK), 0, c->stream, src,
+                               sstride, c->P, c->d_meta, c->d_refs, n_ref, c->W, max_chunks, c->d_act, c->xyz);
+    } else {
+        hipLaunchKernelGGL(k_pointset, dim3(blocks_for(c->P), n_ref), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
+                           c->d_meta, c->d_ref_slots, n_ref, c->W, c->H, c->xyz);
+        // a full rewrite leaves zeros wherever the source is zero: sparse again iff the source was
+        for (int r = 0; r < n_ref; r++)
+            c->xyz_sparse[ref_slots[r]] = (c->recon_lambdaG[ref_slots[r]] == c->dprm.lambdaG) &&
+                                          (!source || c->chk_sparse[ref_slots[r]]);
+    }
     HIP_TRY(hipGetLastError());
     return tables_staged(c);
 }

@@ -444,36 +444,41 @@ __global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict_
     __syncthreads();
 
     unsigned long long n_fused = 0;
-    if (w == 0 && on && nh > prm.lambdaN) {
-        unsigned best = 0;
-        int besta = 0;
-        for (int a = 0; a < n; a++) {
-            if (!((vm >> a) & 1ull)) continue;
-            const unsigned c = cnt[a * K1_PX + p];
-            if (c > best) {  // first largest set wins
-                best = c;
-                besta = a;
+    if (w == 0 && on) {
+        float2 result = make_float2(0.f, 0.f);  // a fresh depth_map_/depth_sigma_ entry (not fused)
+        if (nh > prm.lambdaN) {
+            unsigned best = 0;
+            int besta = 0;
+            for (int a = 0; a < n; a++) {
+                if (!((vm >> a) & 1ull)) continue;
+                const unsigned c = cnt[a * K1_PX + p];
+                if (c > best) {  // first largest set wins
+                    best = c;
+                    besta = a;
+                }
             }
-        }
-        if ((int)best >= prm.lambdaN) {  // PM.cc:623
-            const float2 ha = hyp[besta * K1_PX + p];
-            const float ra = rinv[besta * K1_PX + p];
-            float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
+            if ((int)best >= prm.lambdaN) {  // PM.cc:623
+                const float2 ha = hyp[besta * K1_PX + p];
+                const float ra = rinv[besta * K1_PX + p];
+                float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
 #if SDM_ABLATE == 8
-            pjsj = ha.x; rsj = ra;
-            for (int bb = 0; bb < 0; bb++) {
+                pjsj = ha.x; rsj = ra;
+                for (int bb = 0; bb < 0; bb++) {
 #else
-            for (int bb = 0; bb < n; bb++) {
+                for (int bb = 0; bb < n; bb++) {
 #endif
-                if (!((vm >> bb) & 1ull)) continue;
-                const float2 hb = hyp[bb * K1_PX + p];
-                const bool in = (bb == besta) ? (ha.y * ha.y > 0.0f)
-                                              : chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p]);
-                if (in) fusion_accum(hb.x, hb.y, pjsj, rsj);
+                    if (!((vm >> bb) & 1ull)) continue;
+                    const float2 hb = hyp[bb * K1_PX + p];
+                    const bool in = (bb == besta) ? (ha.y * ha.y > 0.0f)
+                                                  : chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p]);
+                    if (in) fusion_accum(hb.x, hb.y, pjsj, rsj);
+                }
+                result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
+                n_fused = 1;
             }
-            pool[(long long)rc.slot * plane + y * W + x] = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
-            n_fused = 1;
         }
+        // every listed pixel is written (fused value or zero); pixels outside the list are zero already
+        pool[(long long)rc.slot * plane + y * W + x] = result;
     }
     if (STATS) {
         unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass,
@@ -844,8 +849,8 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict_
 
 // Pipeline form: the depth map was produced by SemiDenseRecon, so every supported pixel is in the
 // keyframe's active-pixel list (K1 writes only listed pixels, K2 only removes support, K3 grows
-// only pixels with GradImg >= lambdaG).  One thread per list entry, no LDS; k_rho_copy has already
-// copied rho into the checked plane.
+// only pixels with GradImg >= lambdaG).  One thread per list entry, no LDS; every listed pixel of the
+// checked plane is written, the rest of it must already equal rho (= 0) -- else k_rho_copy runs first.
 __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __restrict__ pool, long long plane,
                                                             const RefConst* __restrict__ refs,
                                                             const PairConst* __restrict__ pairs, int n_ref, int n,
@@ -865,8 +870,10 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __rest
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const long long o = (long long)rc.slot * plane + y * W + x;
     const float depthp = pool[o].x;
-    if ((double)depthp < 0.000001) return;  // PM.cc:662 (the checked plane already holds rho)
-    chk[o] = inter_check_pixel(pool, plane, rc, pairs + (long long)ref * n, n, W, H, x, y, depthp, lambdaN);
+    float out = depthp;  // PM.cc:662: skipped pixels keep their value
+    if (!((double)depthp < 0.000001))
+        out = inter_check_pixel(pool, plane, rc, pairs + (long long)ref * n, n, W, H, x, y, depthp, lambdaN);
+    chk[o] = out;
 }
 
 // rho plane of the depth map -> checked plane
@@ -915,6 +922,46 @@ __global__ __launch_bounds__(BLOCK) void k_pointset(const float* __restrict__ sr
     mat3_vec(Rwc, tcw, Ow);
     float inv_d = src_base[((long long)slot * plane + idx) * sstride];
     float* o = xyz + ((long long)slot * plane + idx) * 3;
+    if ((double)inv_d < 0.000001) {  // PM.cc:345
+        o[0] = 0.f;
+        o[1] = 0.f;
+        o[2] = 0.f;
+        return;
+    }
+    float Z = 1 / inv_d;
+    float X = Z * ((float)x - m.cx) / m.fx;
+    float Y = Z * ((float)y - m.cy) / m.fy;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = ((Rwc[i * 3 + 0] * X + Rwc[i * 3 + 1] * Y) + Rwc[i * 3 + 2] * Z) + (-Ow[i]) * 1.0f;
+}
+
+// K5, pipeline form: the source map is zero outside the keyframe's active list and the xyz plane is zero
+// there already, so only listed pixels are (re)written.
+__global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict__ src_base, int sstride,
+                                                         long long plane, const KfMeta* __restrict__ meta,
+                                                         const RefConst* __restrict__ refs, int n_ref, int W,
+                                                         int max_chunks, const unsigned* __restrict__ act,
+                                                         float* __restrict__ xyz)
+{
+    const int b = blockIdx.x;
+    const int i8 = b >> 3;
+    const int cl = i8 / n_ref;
+    const int r = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
+    const RefConst rc = refs[r];
+    const int t = chunk * BLOCK + threadIdx.x;
+    if (t >= rc.act_count) return;
+    const unsigned xy = act[(long long)rc.slot * plane + t];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const KfMeta m = meta[rc.slot];
+    float Rwc[9], Ow[3], tcw[3] = {m.Tcw[3], m.Tcw[7], m.Tcw[11]};  // Twc, src/KeyFrame.cc:70-84
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) Rwc[i * 3 + k] = m.Tcw[k * 4 + i];
+    mat3_vec(Rwc, tcw, Ow);
+    const long long idx = (long long)rc.slot * plane + y * W + x;
+    float inv_d = src_base[idx * sstride];
+    float* o = xyz + idx * 3;
     if ((double)inv_d < 0.000001) {  // PM.cc:345
         o[0] = 0.f;
         o[1] = 0.f;

@@ -272,6 +272,51 @@ def test_list_kernels_on_declared_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
     eng.close()
 
 
+def test_mixed_generic_and_list_paths(pkg, oracle, gpu_ok, seq_mid):
+    """alternate pipeline maps (list kernels; zero-fill / copy passes skipped) with arbitrary uploaded
+    maps (generic kernels) on the same slots: the sparse-plane bookkeeping must never leak stale data"""
+    seq, n = seq_mid, 7
+    eng = make_engine(pkg, seq, n)
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    rng = np.random.default_rng(33)
+    maps = oracle_pipeline(oracle, seq, n)
+    chk_ref, xyz_ref = oracle_inter(oracle, seq, n, maps)
+
+    def check_pipeline(tag):
+        eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+        eng.inter_check(refs, nbrs)
+        eng.pointset(refs, source=1)
+        for k in refs:
+            r, s = eng.download_depth(k)
+            assert_bit_equal(r, maps["rho"][k], tag + " rho")
+            assert_bit_equal(s, maps["sigma"][k], tag + " sigma")
+            assert_bit_equal(eng.download_checked(k), chk_ref[k], tag + " chk")
+            assert_bit_equal(eng.download_pointset(k), xyz_ref[k], tag + " xyz")
+
+    check_pipeline("first")
+    check_pipeline("repeat (no zero-fill, no copy)")
+    # arbitrary dense maps on every slot -> generic K4/K5, planes become non-sparse
+    rho, sig = {}, {}
+    for k in refs:
+        rho[k], sig[k] = crafted_maps(rng, seq.H, seq.W, density=0.9, orphan_sigma_frac=0.0)
+        rho[k][rho[k] > 0] = (seq.gt[k] * (1 + 0.01 * rng.standard_normal((seq.H, seq.W))).astype(np.float32))[rho[k] > 0]
+        eng.upload_depth(k, rho[k], sig[k])
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    eng.pointset(refs[:3], source=0)
+    for k in refs:
+        ref = oracle.inter_check(seq.okf[k], rho[k], [seq.okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                                 [sig[j] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), ref, "generic chk")
+        want = oracle.pointset(seq.okf[k], rho[k] if k < 3 else ref)
+        assert_bit_equal(eng.download_pointset(k), want, "generic xyz")
+    # back to the pipeline: stale dense data in pool/chk/xyz must be cleared
+    check_pipeline("after generic")
+    check_pipeline("after generic, repeat")
+    eng.close()
+
+
 def test_growing_is_noop_on_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
     """after K1+K2 every rho<1e-6 pixel has sigma 0, so K3 changes nothing"""
     eng = make_engine(pkg, seq_mid, 7)
