@@ -194,7 +194,7 @@ def main():
             "bound": "hbm", "kernel": "k_search_fuse",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": k1_traffic(args, len(own), k1_n, args.steps),
             "launch_ms": round(k1_avg_ms, 4), "launches": k1_n,
             "algorithmic_bytes_per_launch": k1_bytes,
         },
@@ -217,6 +217,22 @@ def main():
         out["host_upload_ms_per_keyframe"] = round(t_h2d * 1e3, 4)
         out["value_pcie_inclusive"] = round(P * n_total / (dt / args.steps + t_h2d * len(own)) / 1e6, 2)
     print(json.dumps(out))
+
+
+def k1_traffic(args, n_own, k1_launches, steps):
+    """HBM-side bytes of one k_search_fuse launch, from the committed PMC run of the same workload
+    (profiles/r01_traffic.json, produced by tools/pmc.sh: rocprofv3 cannot run inside bench.py).  null
+    when this run's workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    w = t.get("workload", {})
+    if (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity")) != (args.res, args.kfs, args.nbrs, args.disparity):
+        return None
+    if k1_launches != steps:  # profiled with one launch per step (single GPU)
+        return None
+    return t["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H):

@@ -17,3 +17,24 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         v = agg[k][c]
         print("    %-34s %16.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# HBM-side traffic of the dominant kernel from the size-specific request counters (the guide's
+# "calibrate on your own access pattern": FETCH_SIZE tallies every request at 64 B, but K1's gathers
+# leave the L2 as 128-B requests, so bytes = 32*n32 + 64*n64 + 128*n128; writes likewise).
+import json
+k1 = [k for k in agg if "k_search_fuse<false>" in k]
+if k1:
+    c = {n: (sum(v) / len(v)) for n, v in agg[k1[0]].items()}
+    need = ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+    if all(n in c for n in need):
+        rd = 32 * c[need[0]] + 64 * c[need[1]] + 128 * c[need[2]]
+        wr = None
+        if "TCC_EA0_WRREQ_sum" in c and "TCC_EA0_WRREQ_64B_sum" in c:
+            wr = 64 * c["TCC_EA0_WRREQ_64B_sum"] + 32 * (c["TCC_EA0_WRREQ_sum"] - c["TCC_EA0_WRREQ_64B_sum"])
+        out = {"kernel": "k_search_fuse", "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+               "traffic_bytes_per_launch": rd + (wr or 0),
+               "FETCH_SIZE_KB": c.get("FETCH_SIZE"), "WRITE_SIZE_KB": c.get("WRITE_SIZE"),
+               "method": "32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B (+ 64*WRREQ_64B + 32*other WRREQ), "
+                         "TCC_EA0 counters summed over channels, averaged over launches"}
+        json.dump(out, open(root + "/traffic.json", "w"), indent=1)
+        print("traffic.json:", json.dumps(out))
