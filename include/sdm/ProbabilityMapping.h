@@ -20,6 +20,7 @@
 #define SDM_PROBABILITY_MAPPING_H
 
 #include <cstdint>
+#include <iosfwd>
 #include <map>
 #include <vector>
 
@@ -124,6 +125,16 @@ public:
     void ComputeFundamental(sdm::KeyFrame* pKF1, sdm::KeyFrame* pKF2, float F12[9]);
     /* PM.cc:100-132: "v x y z" lines for sigma <= 0.01 and rho > 1e-6; returns the vertex count */
     long SavePointCloudObj(const char* path);
+    /* The step after the path: the keyframe's semi-dense points as a CARV transcript entry,
+     * in the exact text form of SFMTranscriptInterface_ORBSLAM::addKeyFrameInsertionWithLinesEntry
+     * (src/Modeler/SFMTranscriptInterface_ORBSLAM.cpp:319-374):
+     *     new cam: [x; y; z] {
+     *     new point: [x; y; z], <camIndex>, <camIndexOriginal>
+     *     }
+     * points = pixels with sigma <= 0.01 and rho > 1e-6 (the obj writer's filter, PM.cc:120-121), raster
+     * order; numbers through operator<<(double) like the reference.  Returns the number of points. */
+    long AppendTranscriptEntry(sdm::KeyFrame* kf, int camIndex, int camIndexOriginal, std::ostream& out,
+                               double max_sigma = 0.01);
     bool ok() const { return ctx_ != nullptr; }
 
 private:

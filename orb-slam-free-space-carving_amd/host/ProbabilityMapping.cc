@@ -364,3 +364,32 @@ long ProbabilityMapping::SavePointCloudObj(const char* path)
     out.flush();
     return n;
 }
+
+// SFMTranscriptInterface_ORBSLAM.cpp:319-374 (addKeyFrameInsertionWithLinesEntry): text form only.
+long ProbabilityMapping::AppendTranscriptEntry(sdm::KeyFrame* kf, int camIndex, int camIndexOriginal, std::ostream& out,
+                                               double max_sigma)
+{
+    if (!kf || kf->SemiDensePointSets_.empty()) return -1;
+    // camera centre = translation of Twc = -Rcw^T * tcw (src/KeyFrame.cc:70-84), float, left-to-right sums
+    float Ow[3];
+    for (int i = 0; i < 3; i++) {
+        float p0 = kf->Tcw[0 * 4 + i] * kf->Tcw[3];
+        float p1 = kf->Tcw[1 * 4 + i] * kf->Tcw[7];
+        float p2 = kf->Tcw[2 * 4 + i] * kf->Tcw[11];
+        Ow[i] = -((p0 + p1) + p2);
+    }
+    out << "new cam: [" << (double)Ow[0] << "; " << (double)Ow[1] << "; " << (double)Ow[2] << "] {" << std::endl;
+    long n = 0;
+    for (int y = 0; y < kf->im_.rows; y++)
+        for (int x = 0; x < kf->im_.cols; x++) {
+            if (kf->depth_sigma_.at(y, x) > max_sigma) continue;  // PM.cc:120 (0.01)
+            if (!(kf->depth_map_.at(y, x) > 0.000001)) continue;  // PM.cc:121
+            out << "new point: [" << (double)kf->SemiDensePointSets_.at(y, 3 * x) << "; "
+                << (double)kf->SemiDensePointSets_.at(y, 3 * x + 1) << "; "
+                << (double)kf->SemiDensePointSets_.at(y, 3 * x + 2) << "]"
+                << ", " << camIndex << ", " << camIndexOriginal << std::endl;
+            n++;
+        }
+    out << "}" << std::endl;
+    return n;
+}

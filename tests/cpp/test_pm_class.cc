@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <vector>
 
 #include "sdm/ProbabilityMapping.h"
@@ -98,6 +99,11 @@ int main(int argc, char** argv)
     kfs[4].poseChanged = true;
     pm.UpdateAllSemiDensePointSet();
     long nv = pm.SavePointCloudObj(argc > 3 ? argv[3] : "/dev/null");
+    if (argc > 4) {  // CARV transcript entries of keyframes 2 and 3
+        std::ofstream tr(argv[4]);
+        pm.AppendTranscriptEntry(&kfs[2], 7, 2, tr);
+        pm.AppendTranscriptEntry(&kfs[3], 8, 3, tr, 0.25);  // a looser sigma filter so that points are emitted
+    }
 
     FILE* o = fopen(argv[2], "wb");
     if (!o) return 2;

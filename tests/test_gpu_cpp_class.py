@@ -46,7 +46,8 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path):
             depths[k].tofile(f)
     out = tmp_path / "out.bin"
     obj = tmp_path / "cloud.obj"
-    subprocess.check_call([exe, str(blob), str(out), str(obj)])
+    tr = tmp_path / "transcript.txt"
+    subprocess.check_call([exe, str(blob), str(out), str(obj), str(tr)])
 
     # ---- the same schedule on the oracle ----------------------------------------------------------
     nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
@@ -116,3 +117,22 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path):
     nv = sum(int(((sig[k] <= 0.01) & (rho[k] > 1e-6)).sum()) for k in range(n_kf) if inter[k])
     assert int(misc[7]) == nv
     assert sum(1 for line in open(obj) if line.startswith("v ")) == nv
+
+    # CARV transcript entries (SFMTranscriptInterface_ORBSLAM.cpp:319-374): exact text
+    want = []
+    for k, cam, orig, max_sigma in ((2, 7, 2, 0.01), (3, 8, 3, 0.25)):
+        T = seq.Tcw[k].astype(np.float32)
+        Ow = [-np.float32((np.float32(T[0, i] * T[0, 3]) + np.float32(T[1, i] * T[1, 3])) + np.float32(T[2, i] * T[2, 3]))
+              for i in range(3)]
+        want.append("new cam: [%s; %s; %s] {" % tuple("%g" % float(v) for v in Ow))
+        P = xyz[k].reshape(H, W, 3)
+        for yy in range(H):
+            for xx in range(W):
+                if float(sig[k][yy, xx]) > max_sigma or not rho[k][yy, xx] > 1e-6:
+                    continue
+                want.append("new point: [%s; %s; %s], %d, %d" % (tuple("%g" % float(v) for v in P[yy, xx]) + (cam, orig)))
+        want.append("}")
+    got = open(tr).read().split("\n")
+    assert got[-1] == ""
+    assert got[:-1] == want
+    assert sum(1 for l in want if l.startswith("new point")) > 50
