@@ -95,7 +95,7 @@ def main():
     # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as
     # HOST gray images through sdm_upload_image (H2D copy + device pre-pass + record packing)
     t_h2d = None
-    if rank == 0 and images:
+    if rank == 0 and world == 1 and images:
         ks = sorted(images)[:16]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -207,16 +207,16 @@ def main():
         }
 
     # ---- CPU baseline: the oracle (a port; the reference itself cannot be built) on a bounded sample
-    if args.cpu_kfs > 0:
+    if args.cpu_kfs > 0 and world == 1:  # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H)
-    eng.close()
-    if world > 1:
-        dist.destroy_process_group()
     out["gen_s"] = round(t_gen, 2)
     if t_h2d is not None:
         out["host_upload_ms_per_keyframe"] = round(t_h2d * 1e3, 4)
         out["value_pcie_inclusive"] = round(P * n_total / (dt / args.steps + t_h2d * len(own)) / 1e6, 2)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)  # the result line first; teardown cannot lose it
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def k1_traffic(args, n_own, k1_launches, steps):
