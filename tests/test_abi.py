@@ -88,3 +88,20 @@ def test_product_does_not_touch_oracle():
                     if re.search(r"pm_oracle|pmo_|oracle/", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_class_library_exports_reference_surface(pkg):
+    """libsdm_pm.so loads and defines every public method of the reference's class surface (PM.h:72-91)"""
+    import subprocess
+    lib = os.path.join(os.path.dirname(pkg.lib_path()), "libsdm_pm.so")
+    assert os.path.exists(lib), "run __graft_entry__.build()"
+    ctypes.CDLL(pkg.lib_path(), mode=ctypes.RTLD_GLOBAL)
+    ctypes.CDLL(lib)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib]).decode()
+    for m in ["ProbabilityMapping::ProbabilityMapping(", "ProbabilityMapping::SemiDenseRecon(",
+              "ProbabilityMapping::StereoSearchConstraints(", "ProbabilityMapping::EpipolarSearch(",
+              "ProbabilityMapping::GetSearchRange(", "ProbabilityMapping::InverseDepthHypothesisFusion(",
+              "ProbabilityMapping::IntraKeyFrameDepthChecking(", "ProbabilityMapping::IntraKeyFrameDepthGrowing(",
+              "ProbabilityMapping::UpdateSemiDensePointSet(", "ProbabilityMapping::UpdateAllSemiDensePointSet(",
+              "ProbabilityMapping::InterKeyFrameDepthChecking(", "ProbabilityMapping::AppendTranscriptEntry("]:
+        assert m in syms, m

@@ -444,6 +444,31 @@ def test_batch_invariance(pkg, oracle, gpu_ok, seq_mid):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 33, 64])
+def test_neighbour_count_edges(pkg, oracle, gpu_ok, n):
+    """covisN from 1 (nothing can fuse: PM.cc:221 needs > 3 hypotheses) to the 64-neighbour maximum
+    (validity masks beyond 32 bits, > 64 KB of LDS hypotheses)"""
+    n_kf = max(n + 1, 8)
+    seq = Sequence(pkg, oracle, 64, 48, n_kf, 0x5EED0B00 + n, disparity_px=0.4 if n > 8 else 2.6)
+    eng = make_engine(pkg, seq, n)
+    refs = [0, n_kf // 2, n_kf - 1]
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    eng.inter_check(refs, nbrs)
+    fused = 0
+    for i, k in enumerate(refs):
+        r, s, _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[i]], None, seq.min_depth, seq.max_depth)
+        g = eng.download_depth(k)
+        assert_bit_equal(g[0], r, "rho n=%d" % n)
+        assert_bit_equal(g[1], s, "sigma n=%d" % n)
+        fused += int((r > 1e-6).sum())
+    if n <= 3:
+        assert fused == 0
+    if n >= 5:
+        assert fused > 50
+    eng.close()
+
+
 def test_noise_images(pkg, oracle, gpu_ok):
     """adversarial i.i.d. uniform images: nearly nothing fuses, scan-only path"""
     seq = Sequence(pkg, oracle, 96, 64, 8, 0x5EED0A04, noise=True)
