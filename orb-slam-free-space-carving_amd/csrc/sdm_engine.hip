@@ -76,14 +76,23 @@ struct sdm_ctx {
     unsigned long long* d_sums = nullptr;
     float* d_small = nullptr;  // 16 floats of per-pixel results
 
-    // per-call tables (device + pinned host mirrors)
+    // per-call tables: one packed device block + pinned host mirror, staged with a single copy.
+    // The pointers below are carved out of it per call; a call whose tables equal the previous call's
+    // (same slots, same constants, nothing re-uploaded since) reuses them without any copy or set-up kernel.
     int cap_refs = 0;
-    int *d_ref_slots = nullptr, *h_ref_slots = nullptr;
-    int *d_nbr_slots = nullptr, *h_nbr_slots = nullptr;
-    float *d_rot = nullptr, *h_rot = nullptr;
-    float *d_mind = nullptr, *h_mind = nullptr;
-    float *d_maxd = nullptr, *h_maxd = nullptr;
-    long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of cap_refs
+    unsigned char *d_tab = nullptr, *h_tab = nullptr;
+    size_t tab_bytes = 0;
+    int *d_ref_slots = nullptr, *d_nbr_slots = nullptr;
+    float *d_rot = nullptr, *d_mind = nullptr, *d_maxd = nullptr;
+    long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of n_ref: pool, scratch, record
+    struct TableKey {
+        bool valid = false, has_consts = false;
+        int n_ref = 0, n = 0;
+        unsigned long long epoch = 0;
+        std::vector<int> refs, nbrs;
+        std::vector<float> rot, mind, maxd;
+    } tkey;
+    unsigned long long epoch = 1;  // bumped whenever poses, intrinsics, lists or slots change
     RefConst* d_refs = nullptr;
     PairConst* d_pairs = nullptr;
     hipEvent_t tables_free = nullptr;
@@ -136,6 +145,7 @@ int build_active(sdm_ctx* c, int slot)
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->act_lambdaG[slot] = c->dprm.lambdaG;
+    c->epoch++;
     return SDM_OK;
 }
 
@@ -181,9 +191,10 @@ struct StageTimer {
     }
 };
 
-// upload slot tables for a call; builds RefConst/PairConst on device when n > 0
+// Stage the tables of a call (slot lists, per-reference offsets, search constants) and build
+// RefConst/PairConst on device.  need_consts: rot/mind/maxd matter (K1); otherwise any cached value is fine.
 int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, const float* rot,
-                 const float* mind, const float* maxd)
+                 const float* mind, const float* maxd, bool need_consts = false)
 {
     if (n_ref <= 0 || !ref_slots) return fail(SDM_EINVAL, "n_ref <= 0 or null ref_slots");
     if (n_ref > c->cap_refs) return fail(SDM_EINVAL, "n_ref exceeds max_keyframes");
@@ -197,50 +208,92 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
             if (rc) return rc;
         }
     }
-    int rc = wait_tables(c);
-    if (rc) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc;
     for (int r = 0; r < n_ref; r++)  // lists follow lambdaG (sdm_set_params)
         if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG))
             if ((rc = build_active(c, ref_slots[r]))) return rc;
-    memcpy(c->h_ref_slots, ref_slots, sizeof(int) * n_ref);
-    HIP_TRY(hipMemcpyAsync(c->d_ref_slots, c->h_ref_slots, sizeof(int) * n_ref, hipMemcpyHostToDevice, c->stream));
-    if (n > 0) {
-        size_t np = (size_t)n_ref * n;
-        memcpy(c->h_nbr_slots, nbr_slots, sizeof(int) * np);
-        if (rot)
-            memcpy(c->h_rot, rot, sizeof(float) * np);
-        else
-            memset(c->h_rot, 0, sizeof(float) * np);
-        for (int r = 0; r < n_ref; r++) {
-            c->h_mind[r] = mind ? mind[r] : 0.f;
-            c->h_maxd[r] = maxd ? maxd[r] : 0.f;
+
+    const size_t np = (size_t)n_ref * (size_t)n;
+    sdm_ctx::TableKey& k = c->tkey;
+    bool hit = k.valid && k.epoch == c->epoch && k.n_ref == n_ref &&
+               memcmp(k.refs.data(), ref_slots, sizeof(int) * n_ref) == 0;
+    if (hit && n > 0) hit = (k.n == n) && memcmp(k.nbrs.data(), nbr_slots, sizeof(int) * np) == 0;
+    if (hit && need_consts) {
+        hit = k.has_consts && memcmp(k.mind.data(), mind, sizeof(float) * n_ref) == 0 &&
+              memcmp(k.maxd.data(), maxd, sizeof(float) * n_ref) == 0;
+        if (hit) {
+            if (rot)
+                hit = memcmp(k.rot.data(), rot, sizeof(float) * np) == 0;
+            else
+                for (size_t i = 0; i < np && hit; i++) hit = (k.rot[i] == 0.0f);
         }
-        HIP_TRY(hipMemcpyAsync(c->d_nbr_slots, c->h_nbr_slots, sizeof(int) * np, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_rot, c->h_rot, sizeof(float) * np, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_mind, c->h_mind, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_maxd, c->h_maxd, sizeof(float) * n_ref, hipMemcpyHostToDevice, c->stream));
+    }
+    if (hit) return SDM_OK;
+
+    if ((rc = wait_tables(c))) return rc;
+    // packed layout (4-byte units): refs[n_ref] nbrs[np] rot[np] mind[n_ref] maxd[n_ref] | 8-byte: off[3*n_ref]
+    size_t words = (size_t)n_ref * 3 + np * 2;
+    words = (words + 1) & ~(size_t)1;
+    const size_t bytes = words * 4 + sizeof(long long) * 3 * (size_t)n_ref;
+    if (bytes > c->tab_bytes) return fail(SDM_EINVAL, "table staging overflow");
+    int* h_refs = reinterpret_cast<int*>(c->h_tab);
+    int* h_nbrs = h_refs + n_ref;
+    float* h_rot = reinterpret_cast<float*>(h_nbrs + np);
+    float* h_mind = h_rot + np;
+    float* h_maxd = h_mind + n_ref;
+    c->h_off = reinterpret_cast<long long*>(c->h_tab + words * 4);
+    c->d_ref_slots = reinterpret_cast<int*>(c->d_tab);
+    c->d_nbr_slots = c->d_ref_slots + n_ref;
+    c->d_rot = reinterpret_cast<float*>(c->d_nbr_slots + np);
+    c->d_mind = c->d_rot + np;
+    c->d_maxd = c->d_mind + n_ref;
+    c->d_off = reinterpret_cast<long long*>(c->d_tab + words * 4);
+    memcpy(h_refs, ref_slots, sizeof(int) * n_ref);
+    if (np) memcpy(h_nbrs, nbr_slots, sizeof(int) * np);
+    for (size_t i = 0; i < np; i++) h_rot[i] = rot ? rot[i] : 0.0f;
+    const int cap = c->cfg.batch_capacity;
+    for (int r = 0; r < n_ref; r++) {
+        h_mind[r] = mind ? mind[r] : 0.f;
+        h_maxd[r] = maxd ? maxd[r] : 0.f;
+        c->h_off[r] = (long long)ref_slots[r] * c->P;              // depth-pool offset
+        c->h_off[n_ref + r] = (long long)(r % cap) * c->P;         // scratch offset
+        c->h_off[2 * n_ref + r] = (long long)ref_slots[r] * c->P * 4;  // record offset in floats
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_tab, c->h_tab, bytes, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
         hipLaunchKernelGGL(k_pair_setup, dim3(blocks_for((long long)np)), dim3(BLOCK), 0, c->stream, c->d_meta,
                            c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, n_ref, n,
                            c->d_refs, c->d_pairs);
-        HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_ref_setup, dim3(blocks_for(n_ref)), dim3(BLOCK), 0, c->stream, c->d_meta, c->d_ref_slots,
                            c->d_act_count, n_ref, c->d_refs);
-        HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipGetLastError());
+    k.valid = true;
+    k.has_consts = (n > 0) && mind && maxd;
+    k.n_ref = n_ref;
+    k.n = n;
+    k.epoch = c->epoch;
+    k.refs.assign(ref_slots, ref_slots + n_ref);
+    k.nbrs.assign(nbr_slots, nbr_slots + np);
+    k.rot.assign(h_rot, h_rot + np);
+    k.mind.assign(h_mind, h_mind + n_ref);
+    k.maxd.assign(h_maxd, h_maxd + n_ref);
+    HIP_TRY(hipEventRecord(c->tables_free, c->stream));  // the pinned block may be rewritten after this point
+    c->tables_pending = true;
     return SDM_OK;
 }
 
 int tables_staged(sdm_ctx* c)
 {
-    HIP_TRY(hipEventRecord(c->tables_free, c->stream));
-    c->tables_pending = true;
+    (void)c;  // the staging block is released by the event recorded in stage_tables
     return SDM_OK;
 }
 
 int push_meta(sdm_ctx* c, int slot)
 {
+    c->epoch++;
     HIP_TRY(hipMemcpyAsync(c->d_meta + slot, &c->h_meta[slot], sizeof(KfMeta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SDM_OK;
@@ -249,6 +302,7 @@ int push_meta(sdm_ctx* c, int slot)
 // a keyframe uploaded into a slot starts with fresh (zero) maps and no stage flags
 int reset_slot(sdm_ctx* c, int slot)
 {
+    c->epoch++;
     c->has_depth[slot] = 0;
     c->has_chk[slot] = 0;
     c->recon_lambdaG[slot] = std::nanf("");
@@ -423,12 +477,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_small, 16))) return bail(rc);
     if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
     const size_t np = (size_t)K * cfg->max_neighbours;
-    if ((rc = dev_alloc(&c->d_ref_slots, K)) || (rc = host_alloc(&c->h_ref_slots, K))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_nbr_slots, np)) || (rc = host_alloc(&c->h_nbr_slots, np))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_rot, np)) || (rc = host_alloc(&c->h_rot, np))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_mind, K)) || (rc = host_alloc(&c->h_mind, K))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_maxd, K)) || (rc = host_alloc(&c->h_maxd, K))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_off, (size_t)3 * K)) || (rc = host_alloc(&c->h_off, (size_t)3 * K))) return bail(rc);
+    c->tab_bytes = 4 * ((size_t)K * 3 + np * 2 + 2) + sizeof(long long) * 3 * (size_t)K;
+    if ((rc = dev_alloc(&c->d_tab, c->tab_bytes)) || (rc = host_alloc(&c->h_tab, c->tab_bytes))) return bail(rc);
     if ((rc = dev_alloc(&c->d_refs, K)) || (rc = dev_alloc(&c->d_pairs, np))) return bail(rc);
     if ((rc = host_alloc(&c->h_f2, (size_t)c->P))) return bail(rc);
     if (hipEventCreateWithFlags(&c->tables_free, hipEventDisableTiming) != hipSuccess)
@@ -477,20 +527,10 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_sums);
     (void)hipFree(c->d_small);
     (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_ref_slots);
-    (void)hipFree(c->d_nbr_slots);
-    (void)hipFree(c->d_rot);
-    (void)hipFree(c->d_mind);
-    (void)hipFree(c->d_maxd);
-    (void)hipFree(c->d_off);
+    (void)hipFree(c->d_tab);
     (void)hipFree(c->d_refs);
     (void)hipFree(c->d_pairs);
-    (void)hipHostFree(c->h_ref_slots);
-    (void)hipHostFree(c->h_nbr_slots);
-    (void)hipHostFree(c->h_rot);
-    (void)hipHostFree(c->h_mind);
-    (void)hipHostFree(c->h_maxd);
-    (void)hipHostFree(c->h_off);
+    (void)hipHostFree(c->h_tab);
     (void)hipHostFree(c->h_f2);
     if (c->tables_free) (void)hipEventDestroy(c->tables_free);
     for (auto& sp : c->spans) {
@@ -640,7 +680,7 @@ int sdm_search_fuse(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
     if (!c) return fail(SDM_EINVAL, "null context");
     if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
     if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
-    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
+    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd, true);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;
     for (int r = 0; r < n_ref; r++) {
@@ -652,10 +692,10 @@ int sdm_search_fuse(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
 
 // stencil passes over [first, first+count) of the staged reference list.
 // mode 0: check pool -> scratch; mode 1: grow scratch -> pool; mode 2: check pool->scratch then copy back
-static int launch_intra(sdm_ctx* c, int first, int count, bool check, bool grow)
+static int launch_intra(sdm_ctx* c, int n_ref, int first, int count, bool check, bool grow)
 {
     // offsets: [0..K) pool offsets, [K..2K) scratch offsets, [2K..3K) record offsets (in floats)
-    const int K = c->cap_refs;
+    const int K = n_ref;  // offset tables are [3][n_ref]
     const int grid = grid_blocks(c->geom, count);
     if (check) {
         hipLaunchKernelGGL(k_intra_check, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
@@ -671,28 +711,13 @@ static int launch_intra(sdm_ctx* c, int first, int count, bool check, bool grow)
     return SDM_OK;
 }
 
-static int stage_offsets(sdm_ctx* c, int n_ref, const int* ref_slots)
-{
-    const int K = c->cap_refs, cap = c->cfg.batch_capacity;
-    for (int r = 0; r < n_ref; r++) {
-        c->h_off[r] = (long long)ref_slots[r] * c->P;
-        c->h_off[K + r] = (long long)(r % cap) * c->P;
-        c->h_off[2 * K + r] = (long long)ref_slots[r] * c->P * 4;
-    }
-    for (int k = 0; k < 3; k++)
-        HIP_TRY(hipMemcpyAsync(c->d_off + k * K, c->h_off + k * K, sizeof(long long) * n_ref, hipMemcpyHostToDevice,
-                               c->stream));
-    return SDM_OK;
-}
-
 // K2/K3 on "pipeline" maps (zero outside the keyframe's active list: written by K1, or declared so by
 // sdm_assume_pipeline_maps).  RefConst (act_count, slot) of the staged batch is valid here.
 static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bool grow)
 {
-    int rc = stage_offsets(c, n_ref, ref_slots);
-    if (rc) return rc;
+    int rc = SDM_OK;
     StageTimer tm(c, SDM_STAGE_INTRA);
-    const int K = c->cap_refs, cap = c->cfg.batch_capacity;
+    const int K = n_ref, cap = c->cfg.batch_capacity;  // offset tables are [3][n_ref], staged with the tables
     for (int first = 0; first < n_ref; first += cap) {
         const int count = std::min(cap, n_ref - first);
         int max_chunks = 0;
@@ -733,16 +758,15 @@ static bool all_pipeline_maps(sdm_ctx* c, int n_ref, const int* ref_slots)
 static int run_intra(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bool grow)
 {
     // K2 writes scratch, K3 writes back to the pool.  A lone pass is completed by a device copy.
-    int rc = stage_offsets(c, n_ref, ref_slots);
-    if (rc) return rc;
+    int rc = SDM_OK;
     StageTimer tm(c, SDM_STAGE_INTRA);
     const int cap = c->cfg.batch_capacity;
     for (int first = 0; first < n_ref; first += cap) {
         const int count = std::min(cap, n_ref - first);
         if (check && grow) {
-            if ((rc = launch_intra(c, first, count, true, true))) return rc;
+            if ((rc = launch_intra(c, n_ref, first, count, true, true))) return rc;
         } else if (check) {
-            if ((rc = launch_intra(c, first, count, true, false))) return rc;
+            if ((rc = launch_intra(c, n_ref, first, count, true, false))) return rc;
             for (int r = 0; r < count; r++)
                 HIP_TRY(hipMemcpyAsync(c->pool + c->h_off[first + r], c->scratch + (long long)r * c->P,
                                        sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
@@ -750,7 +774,7 @@ static int run_intra(sdm_ctx* c, int n_ref, const int* ref_slots, bool check, bo
             for (int r = 0; r < count; r++)
                 HIP_TRY(hipMemcpyAsync(c->scratch + (long long)r * c->P, c->pool + c->h_off[first + r],
                                        sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
-            if ((rc = launch_intra(c, first, count, false, true))) return rc;
+            if ((rc = launch_intra(c, n_ref, first, count, false, true))) return rc;
         }
     }
     return SDM_OK;
@@ -788,7 +812,7 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     if (!c) return fail(SDM_EINVAL, "null context");
     if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
     if (!mind || !maxd) return fail(SDM_EINVAL, "null depth bounds");
-    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd);
+    int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd, true);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
     if ((rc = run_intra_lists(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
@@ -966,12 +990,15 @@ static int intra_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad, b
     int rc = wait_tables(c);
     if (rc) return rc;
     if ((rc = upload_f2(c, c->scratch, rho, sigma))) return rc;
-    const int K = c->cap_refs;
+    // private use of the staging block: [in, out, grad] offsets of one map; the cached tables are gone
+    c->tkey.valid = false;
+    c->h_off = reinterpret_cast<long long*>(c->h_tab);
+    c->d_off = reinterpret_cast<long long*>(c->d_tab);
+    const int K = 1;
     c->h_off[0] = 0;
     c->h_off[K] = c->P;
     c->h_off[2 * K] = 0;
-    for (int k = 0; k < 3; k++)
-        HIP_TRY(hipMemcpyAsync(c->d_off + k * K, c->h_off + k * K, sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_off, c->h_off, sizeof(long long) * 3, hipMemcpyHostToDevice, c->stream));
     const int grid = grid_blocks(c->geom, 1);
     if (!grow) {
         hipLaunchKernelGGL(k_intra_check, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->scratch, c->d_off,
@@ -1008,7 +1035,7 @@ int sdm_epipolar_search(sdm_ctx* c, int ref_slot, int nbr_slot, int x, int y, fl
 {
     if (!c || !out) return fail(SDM_EINVAL, "null argument");
     if (x < 0 || x >= c->W || y < 0 || y >= c->H) return fail(SDM_EINVAL, "pixel out of range");
-    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, &rot, &mind, &maxd);
+    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, &rot, &mind, &maxd, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_epipolar_search_px, dim3(1), dim3(1), 0, c->stream, c->rec, c->P, c->d_refs, c->d_pairs, c->W,
                        c->H, x, y, c->dprm, c->d_small);
@@ -1021,7 +1048,7 @@ int sdm_search_range(sdm_ctx* c, int ref_slot, int nbr_slot, int x, int y, float
                      float* umax)
 {
     if (!c || !umin || !umax) return fail(SDM_EINVAL, "null argument");
-    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, nullptr, &mind, &maxd);
+    int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, nullptr, &mind, &maxd, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_search_range_px, dim3(1), dim3(1), 0, c->stream, c->d_refs, c->d_pairs, c->W, x, y, c->d_small);
     HIP_TRY(hipGetLastError());
