@@ -339,8 +339,11 @@ __host__ __device__ inline size_t k1_lds_bytes(int n)
            sizeof(unsigned long long) * BLOCK;
 }
 
+#ifndef SDM_K1_LB
+#define SDM_K1_LB __launch_bounds__(BLOCK)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(BLOCK) void k_search_fuse(const float4* __restrict__ rec, long long plane,
+__global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long long plane,
                                                        const RefConst* __restrict__ refs,
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
                                                        int W, int H, int max_chunks, DevParams prm,
