@@ -1,0 +1,104 @@
+"""GPU: randomised geometry fuzzing of the whole path against the oracle -- large rotations, vertical and
+forward baselines (|a/b| > 4 gate, epipoles inside the image), per-keyframe intrinsics, random in-plane
+rotations and depth priors (including swapped / negative / huge bounds), textured and noise images.
+Everything must stay bit-identical, including the NaN/Inf propagation rules of the reference."""
+import math
+
+import numpy as np
+import pytest
+
+from common import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_case(rng, oracle, W, H, n_kf, mode):
+    """returns dict(im, K, Tcw, okf) with random but reproducible content"""
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.zeros((H, W))
+    for _ in range(12):
+        fx_, fy_ = rng.uniform(0.02, 0.5, 2)
+        base += rng.uniform(10, 40) * np.sin(fx_ * xx + fy_ * yy + rng.uniform(0, 6.28))
+    ims, Ks, Ts = [], [], []
+    for k in range(n_kf):
+        shift = rng.integers(-4, 5, 2)
+        im = np.roll(base, tuple(shift), axis=(0, 1)) + 127 + rng.normal(0, 3, (H, W))
+        if mode == "noise":
+            im = rng.integers(0, 256, (H, W)).astype(np.float64)
+        ims.append(np.clip(np.rint(im), 0, 255).astype(np.uint8))
+        f = rng.uniform(0.7, 1.6) * W
+        Ks.append(np.float32([f, f * rng.uniform(0.9, 1.1), W / 2 + rng.uniform(-5, 5), H / 2 + rng.uniform(-5, 5)]))
+        amp = {"small": 0.02, "large": 0.25, "noise": 0.05, "forward": 0.03, "vertical": 0.03}[mode]
+        R = rot(*rng.uniform(-amp, amp, 3))
+        if mode == "forward":
+            t = np.array([rng.normal(0, 0.002), rng.normal(0, 0.002), rng.uniform(-0.1, 0.1)])
+        elif mode == "vertical":
+            t = np.array([rng.normal(0, 0.003), rng.uniform(-0.08, 0.08), rng.normal(0, 0.003)])
+        else:
+            t = rng.uniform(-0.06, 0.06, 3)
+        Ts.append(np.concatenate([R, t[:, None]], axis=1).astype(np.float32))
+    okf = []
+    derived = []
+    for k in range(n_kf):
+        g, th, s = oracle.gradient_prepass(ims[k])
+        derived.append((g, th, s))
+        okf.append(oracle.keyframe(ims[k], g, th, s, Ks[k], Ts[k]))
+    return dict(im=ims, K=Ks, Tcw=Ts, okf=okf, derived=derived)
+
+
+@pytest.mark.parametrize("mode,seed", [("small", 1), ("small", 2), ("large", 3), ("large", 4), ("forward", 5),
+                                       ("vertical", 6), ("noise", 7), ("small", 8), ("large", 9), ("forward", 10)])
+def test_fuzz_whole_path(pkg, oracle, gpu_ok, mode, seed):
+    rng = np.random.default_rng(1000 + seed)
+    W, H, n_kf, n = 72, 56, 7, 5
+    case = make_case(rng, oracle, W, H, n_kf, mode)
+    eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
+    for k in range(n_kf):
+        if k % 2:
+            eng.upload_image(k, case["im"][k], case["K"][k], case["Tcw"][k])
+        else:
+            g, th, s = case["derived"][k]
+            eng.upload_keyframe(k, case["im"][k], g, th, s, case["K"][k], case["Tcw"][k])
+    refs = list(range(n_kf))
+    nbrs = [[int(j) for j in rng.permutation([j for j in range(n_kf) if j != k])[:n]] for k in refs]
+    rots = rng.uniform(-30, 390, (n_kf, n)).astype(np.float32)
+    rots[rng.random((n_kf, n)) < 0.4] = 0
+    priors = [(1.25, 0.83), (0.5, 2.0), (2.0, 0.5), (-1.0, 1.0), (1e-3, 1e3), (1.0, 1.0), (0.9, 1.1)]
+    mind = np.float32([priors[(k + seed) % len(priors)][0] for k in refs])
+    maxd = np.float32([priors[(k + seed) % len(priors)][1] for k in refs])
+    eng.recon(refs, nbrs, mind, maxd, rot=rots)
+    rho, sig = {}, {}
+    fused = 0
+    for k in refs:
+        r, s, st = oracle.semi_dense_recon(case["okf"][k], [case["okf"][j] for j in nbrs[k]], rots[k], float(mind[k]),
+                                           float(maxd[k]))
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, r, "%s/%d rho kf %d" % (mode, seed, k))
+        assert_bit_equal(gs, s, "%s/%d sigma kf %d" % (mode, seed, k))
+        rho[k], sig[k] = r, s
+        fused += st["fused"]
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    for k in refs:
+        c = oracle.inter_check(case["okf"][k], rho[k], [case["okf"][j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                               [sig[j] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), c, "%s/%d checked kf %d" % (mode, seed, k))
+        assert_bit_equal(eng.download_pointset(k), oracle.pointset(case["okf"][k], c), "%s/%d xyz kf %d" % (mode, seed, k))
+    # per-pixel entry point on random pixels, including the image border
+    for _ in range(40):
+        a, b = rng.choice(n_kf, 2, replace=False)
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        got = eng.epipolar_search(int(a), int(b), x, y, float(mind[a]), float(maxd[a]), float(rots[a, 0]))
+        ref = oracle.epipolar_search(case["okf"][a], case["okf"][b], x, y, float(mind[a]), float(maxd[a]), float(rots[a, 0]))
+        assert got["supported"] == ref["supported"]
+        assert_bit_equal(np.float32([got["rho"], got["sigma"], got["best_u"], got["best_v"]]),
+                         np.float32([ref["rho"], ref["sigma"], ref["best_u"], ref["best_v"]]), "pixel search")
+    eng.close()
