@@ -366,6 +366,12 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     // at a time so that four independent 16-byte gathers are in flight per lane.  Fetch addresses
     // are clamped into the image (32-bit byte offsets from a scalar base); validity is decided
     // separately from the unclamped values.
+#if SDM_ABLATE == 10
+    if (ang_pi_rot + th_line + (float)(hi - lo) != 12345.678f) return false;  // keep the set-up alive, skip the rest
+#endif
+#if SDM_ABLATE == 11
+    if (ab + cb + rxxp + rzxp != 12345.678f) return false;  // only a,b,c, the two line quotients and the ray dot products
+#endif
 #if SDM_ABLATE == 6
     hi = lo - 1;
     old_err = ab;

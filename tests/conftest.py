@@ -16,7 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     import sdm_pkg
-    return sdm_pkg.load()
+    mod = sdm_pkg.load()
+    # build the HIP libraries if the tree has none yet (no-op when lib/*.so is newer than the sources);
+    # a missing library is never papered over: load_library() raises and every test fails loudly
+    if not os.path.exists(mod.lib_path()):
+        mod.build_mod.build_all(verbose=True)
+    return mod
 
 
 @pytest.fixture(scope="session")
