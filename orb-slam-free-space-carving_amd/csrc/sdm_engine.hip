@@ -406,7 +406,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if (!out || !cfg) return fail(SDM_EINVAL, "null argument");
     *out = nullptr;
     if (cfg->W < 8 || cfg->H < 8 || cfg->W > 16384 || cfg->H > 16384) return fail(SDM_EINVAL, "bad image size");
-    if ((long long)cfg->W * cfg->H >= (1ll << 31) / 4) return fail(SDM_EINVAL, "image too large");
+    // kernels address records with 32-bit byte offsets inside a plane (16 B per pixel)
+    if ((long long)cfg->W * cfg->H > (1ll << 27)) return fail(SDM_EINVAL, "image too large (more than 2^27 pixels)");
     if (cfg->max_keyframes < 1) return fail(SDM_EINVAL, "max_keyframes < 1");
     if (cfg->max_neighbours < 1 || cfg->max_neighbours > SDM_MAX_NEIGHBOURS)
         return fail(SDM_EINVAL, "max_neighbours out of range");
