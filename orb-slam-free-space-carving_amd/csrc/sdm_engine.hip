@@ -666,10 +666,10 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     const size_t lds = k1_lds_bytes(n);
     const int grid = 8 * ((max_chunks + 7) / 8) * n_ref;
     if (c->stats_on)
-        hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
+        hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
                            c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
     else
-        hipLaunchKernelGGL(k_search_fuse<false>, dim3(grid), dim3(BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
+        hipLaunchKernelGGL(k_search_fuse<false>, dim3(grid), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
                            c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
     HIP_TRY(hipGetLastError());
     return SDM_OK;

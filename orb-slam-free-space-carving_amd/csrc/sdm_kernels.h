@@ -331,16 +331,20 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 // length grows with the baseline and neighbours are ordered by covisibility.
 // LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), their
 // reciprocal variances, and the per-hypothesis compatible-set sizes: 16 B x n x 64 (20 KB at n = 20).
-constexpr int K1_PX = 64;     // active pixels per workgroup
-constexpr int K1_WAVES = 4;   // neighbour stripes
+#ifndef SDM_K1_WAVES
+#define SDM_K1_WAVES 4
+#endif
+constexpr int K1_PX = 64;                // active pixels per workgroup
+constexpr int K1_WAVES = SDM_K1_WAVES;   // neighbour stripes
+constexpr int K1_BLOCK = K1_PX * K1_WAVES;
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
     return (sizeof(float2) + sizeof(float) + sizeof(unsigned)) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1) +
-           sizeof(unsigned long long) * BLOCK;
+           sizeof(unsigned long long) * K1_BLOCK;
 }
 
 #ifndef SDM_K1_LB
-#define SDM_K1_LB __launch_bounds__(BLOCK)
+#define SDM_K1_LB __launch_bounds__(K1_BLOCK)
 #endif
 template <bool STATS>
 __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long long plane,
@@ -419,7 +423,9 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     // waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.  Wave 0
     // then takes the first row with the largest count (PM.cc:616: strict '>') and re-derives only
     // that row's membership for the fusion sum.
-    const unsigned long long vm = pmask[p] | pmask[K1_PX + p] | pmask[2 * K1_PX + p] | pmask[3 * K1_PX + p];
+    unsigned long long vm = 0;
+#pragma unroll
+    for (int q = 0; q < K1_WAVES; q++) vm |= pmask[q * K1_PX + p];
 #if SDM_ABLATE == 1
     const int nh = 0;
     if (vm == 0x123456789ull) pool[0] = make_float2(1.f, 1.f);
@@ -427,8 +433,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     const int nh = __popcll(vm);
 #endif
     if (nh > prm.lambdaN) {  // PM.cc:221
-        for (int i = 0; 4 * i < n; i++) {
-            const int a = 4 * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
+        for (int i = 0; K1_WAVES * i < n; i++) {
+            const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
             if (a >= n || !((vm >> a) & 1ull)) continue;
             const float2 ha = hyp[a * K1_PX + p];
             const float ra = rinv[a * K1_PX + p];
