@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 // hide the gather latency; interleaving j (not blocking it) balances the waves, because the scan
 // length grows with the baseline and neighbours are ordered by covisibility.
 // LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), their
-// reciprocal variances, and the per-hypothesis compatible-set sizes: 16 B x n x 64 (20 KB at n = 20).
+// reciprocal variances, and the per-hypothesis compatible-set sizes (bytes): 13 B x n x 64 + 2 KB (18.3 KB at n = 20).
 #ifndef SDM_K1_WAVES
 #define SDM_K1_WAVES 4
 #endif
@@ -339,7 +339,8 @@ constexpr int K1_WAVES = SDM_K1_WAVES;   // neighbour stripes
 constexpr int K1_BLOCK = K1_PX * K1_WAVES;
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
-    return (sizeof(float2) + sizeof(float) + sizeof(unsigned)) * (size_t)K1_PX * (size_t)(n > 0 ? n : 1) +
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
            sizeof(unsigned long long) * K1_BLOCK;
 }
 
@@ -357,8 +358,11 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* hyp = reinterpret_cast<float2*>(smem_raw);                // [n][64] {rho, sigma}
     float* rinv = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] 1/sigma^2 (NaN = take the exact path)
-    unsigned* cnt = reinterpret_cast<unsigned*>(rinv + (size_t)n * K1_PX);  // [n][64] compatible-set sizes
-    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)n * K1_PX);  // [4][64]
+    // compatible-set sizes (<= n <= 64), one byte each: row a lives in byte a&3 of word [a>>2][64].  a is
+    // wave-uniform, so the shift is a scalar; a 32-bit LDS atomic add of 1<<8*(a&3) cannot carry over.
+    unsigned* cnt = reinterpret_cast<unsigned*>(rinv + (size_t)n * K1_PX);
+    const int cnt_words = (n + 3) >> 2;
+    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -412,8 +416,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         }
         hyp[j * K1_PX + p] = h;
         rinv[j * K1_PX + p] = safe_rcp_sq(h.y);
-        cnt[j * K1_PX + p] = 0u;
     }
+    for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
     pmask[tid] = mymask;
     __syncthreads();
 
@@ -444,10 +448,10 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                 const float2 hb = hyp[bb * K1_PX + p];
                 if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p])) {
                     c++;
-                    atomicAdd(&cnt[bb * K1_PX + p], 1u);
+                    atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
                 }
             }
-            atomicAdd(&cnt[a * K1_PX + p], c);
+            atomicAdd(&cnt[(a >> 2) * K1_PX + p], c << (8 * (a & 3)));
         }
     }
     __syncthreads();
@@ -460,7 +464,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
             int besta = 0;
             for (int a = 0; a < n; a++) {
                 if (!((vm >> a) & 1ull)) continue;
-                const unsigned c = cnt[a * K1_PX + p];
+                const unsigned c = (cnt[(a >> 2) * K1_PX + p] >> (8 * (a & 3))) & 0xffu;
                 if (c > best) {  // first largest set wins
                     best = c;
                     besta = a;
