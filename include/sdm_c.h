@@ -177,7 +177,8 @@ int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long laun
  * which 2: fast matching cost (PM.cc:436) vs the reference expression incl. rounding midpoints;
  * which 3: closed-form angle gates (PM.cc:414-431) vs the reference statement;
  * which 4: GetFusion's shared-reciprocal double quotients (PM.cc:956-957) vs plain divisions;
- * which 5: float quotients sharing a divisor (K4, PM.cc:678-680,782-783) vs IEEE divisions. */
+ * which 5: float quotients sharing a divisor (K4, PM.cc:678-680,782-783) vs IEEE divisions;
+ * which 6: reciprocal + one FMA step (K4/K5, PM.cc:769,777,793,349) vs IEEE 1/b over all 2^32 float inputs. */
 int sdm_selftest(sdm_ctx *ctx, int which, unsigned long long out[2]);
 /* name of the device the context runs on, e.g. "gfx950" */
 const char *sdm_device_arch(sdm_ctx *ctx);

@@ -513,6 +513,26 @@ __device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, f
     rsj = (float)((double)rsj + t_one);
 }
 
+// ---- the reference's "(double)x > 0.000001" / "< 0.000001" tests (PM.cc:345,497,510,560,662,705) ----------
+// 0x358637bd (9.99999997e-7) is the largest float below the double 1e-6 and its successor lies above
+// it, so the double comparison of a widened float is this float comparison (NaN: false both ways).
+__device__ __forceinline__ bool gt_1em6(float x) { return x > __uint_as_float(0x358637bdu); }
+__device__ __forceinline__ bool lt_1em6(float x) { return x <= __uint_as_float(0x358637bdu); }
+
+// ---- correctly rounded reciprocal --------------------------------------------------------------------------
+// 1.0f/b as v_rcp_f32 (<= 1 ulp) plus one FMA residual step.  On gfx950 this is bit-identical to the
+// IEEE quotient for EVERY b with 2^-125 <= |b| < 2^125 (sdm_selftest(6) walks all 2^32 bit patterns);
+// zero, denormal, huge, Inf and NaN operands take the plain division.  ~2.3x cheaper than the
+// v_div_scale/v_div_fmas/v_div_fixup sequence (tools/ubench/rcp.hip).
+__device__ __forceinline__ float rcp_exact(float b)
+{
+    const float ab = fabsf(b);
+    if (__builtin_expect(!((ab >= 0x1p-125f) & (ab < 0x1p125f)), 0)) return 1.0f / b;
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
 // ---- float quotients that share a divisor -------------------------------------------------------------------
 // a/b from r = 1.0f/b (a true, correctly rounded division done once) with two FMA residual
 // corrections (Markstein): bit-identical to the IEEE quotient provided b's significand is not all

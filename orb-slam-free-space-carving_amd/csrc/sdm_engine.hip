@@ -1155,6 +1155,8 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     } else if (which == 5) {
         hipLaunchKernelGGL(k_selftest_quot, dim3(4096), dim3(BLOCK), 0, c->stream, 8192, c->d_stats + 5,
                            c->d_stats + 6);
+    } else if (which == 6) {
+        hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else if (which == 3) {
         hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else {

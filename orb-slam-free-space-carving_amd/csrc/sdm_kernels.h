@@ -409,7 +409,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
             float rho, sigma, bu, bv;
             bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0, xp1,
                                              rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
-            if (ok && (1.0f / rho) > 0.0f) {  // PM.cc:216
+            if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
                 h = make_float2(rho, sigma);
                 mymask |= 1ull << j;
             }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(BLOCK) void k_intra_check(const float2* __restrict_
         float2 c = tile[(ly + 1) * HALO_W + lx + 1];
         outv[L] = c;  // depth_map_new = depth_map.clone(), PM.cc:488-489
         bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);
-        f[i] = inset && ((double)c.x > 0.000001);  // PM.cc:497
+        f[i] = inset && (gt_1em6(c.x));  // PM.cc:497
     }
     const int nAct = block_compact(f, act, wsum);
     __syncthreads();
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_intra_check(const float2* __restrict_
         for (int k = 0; k < 9; k++) {
             if (k == 4) continue;
             float2 v = tile[(ly + k / 3) * HALO_W + lx + (k % 3)];
-            if ((double)v.x > 0.000001 && chi_test(v.x, c.x, v.y, c.y)) {  // PM.cc:510-512
+            if (gt_1em6(v.x) && chi_test(v.x, c.x, v.y, c.y)) {  // PM.cc:510-512
                 if (cnt == 0) tmin = v.y;
                 fusion_accum(v.x, v.y, pjsj, rsj);
                 if ((double)v.y * (double)v.y < (double)tmin * (double)tmin) tmin = v.y;  // PM.cc:958
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(BLOCK) void k_intra_grow(const float2* __restrict__
         float2 c = tile[(ly + 1) * HALO_W + lx + 1];
         outv[L] = c;
         bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);
-        bool cand = inset && ((double)c.x < 0.000001);  // PM.cc:560
+        bool cand = inset && (lt_1em6(c.x));  // PM.cc:560
         if (cand) cand = !(grad[(long long)(y * W + x) * gstride] < lambdaG);  // PM.cc:562
         f[i] = cand;
     }
@@ -673,7 +673,7 @@ __device__ __forceinline__ float2 intra_check_pixel(const float2* __restrict__ i
     const float rc = safe_rcp_sq(c.y);
 #pragma unroll
     for (int k = 0; k < 8; k++) {  // raster order, PM.cc:504-521
-        if ((double)v[k].x > 0.000001 && chi_test_fast(v[k].x, c.x, v[k].y, c.y, safe_rcp_sq(v[k].y), rc)) {
+        if (gt_1em6(v[k].x) && chi_test_fast(v[k].x, c.x, v[k].y, c.y, safe_rcp_sq(v[k].y), rc)) {
             if (cnt == 0) tmin = v[k].y;
             fusion_accum(v[k].x, v[k].y, pjsj, rsj);
             if ((double)v[k].y * (double)v[k].y < (double)tmin * (double)tmin) tmin = v[k].y;
@@ -733,9 +733,9 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
     const float2 c = in[y * W + x];
     float2 o = c;
     if (GROW) {
-        if ((double)c.x < 0.000001) o = intra_grow_pixel(in, W, x, y, c);  // PM.cc:560 (gradient gate = list)
+        if (lt_1em6(c.x)) o = intra_grow_pixel(in, W, x, y, c);  // PM.cc:560 (gradient gate = list)
     } else {
-        if ((double)c.x > 0.000001) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
+        if (gt_1em6(c.x)) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
     }
     out[y * W + x] = o;
 }
@@ -760,6 +760,44 @@ struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizon
 
 // One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764).  Quotients sharing a
 // divisor (the three /depthp, the two /t2, the two /d2sigma) use quot_with_rcp (sdm_device.h).
+// The loop is software-pipelined by one neighbour: the projection into neighbour j+1 and its two
+// 16-byte row loads are issued before the taps of neighbour j are evaluated, so two gathers per lane
+// are in flight while the taps are evaluated (measured neutral at 480p, ~1 % at 1080p).
+struct InterTap {
+    Row2 ra, rb;   // rows y0 and y0+1: {rho,sigma} at x0 and x0+1
+    float depthj;  // PM.cc:684-688
+    float rzxp, t2c;
+    bool valid;    // PM.cc:695
+};
+__device__ __forceinline__ InterTap inter_project(const float2* __restrict__ pool, long long plane,
+                                                  const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1,
+                                                  float xp0, float xp1, float depthp, float dp, bool dp_ok)
+{
+    InterTap o;
+    const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
+    float t0 = quot_with_rcp(row_dot_xp(pc->R + 0, xp0, xp1), depthp, dp, dp_ok) + pc->t[0];  // PM.cc:678
+    float t1 = quot_with_rcp(row_dot_xp(pc->R + 3, xp0, xp1), depthp, dp, dp_ok) + pc->t[1];
+    float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+    float t2 = quot_with_rcp(rzxp, depthp, dp, dp_ok) + pc->t[2];
+    float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
+    float v = pc->nfy * t1 + pc->ncy * t2;
+    const float r2 = rcp_exact(t2);
+    const bool t2_ok = quot_ok_divisor(t2);
+    float xj = quot_with_rcp(u, t2, r2, t2_ok), yj = quot_with_rcp(v, t2, r2, t2_ok);  // PM.cc:680
+    float denom2 = depthp * pc->t[2];
+    o.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    o.rzxp = rzxp;
+    o.t2c = pc->t[2];
+    o.valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
+    // invalid lanes fetch pixel (0,0): the loads stay unconditional, the result is ignored
+    const int x0 = o.valid ? (int)floorf(xj) : 0, y0 = o.valid ? (int)floorf(yj) : 0;
+    // four taps fetched together; order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+    // each image row's two taps are adjacent float2's: one 16-byte (8-byte aligned) load per row
+    o.ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
+    o.rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+    return o;
+}
+
 __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
                                                    long long plane, const RefConst& rc,
                                                    const PairConst* __restrict__ pcs, int n, int W, int H, int x,
@@ -767,43 +805,29 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
 {
     const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
     const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
-    const float dp = 1 / depthp;                                                        // PM.cc:769
+    const float dp = rcp_exact(depthp);                                                 // PM.cc:769
     const bool dp_ok = quot_ok_divisor(depthp);
     int kf_count = 0;
     float sum_Jr = 0.f, sum_JJ = 0.f;
+    if (n <= 0) return (0 < lambdaN) ? 0.0f : rcp_exact(dp + (-sum_Jr) / sum_JJ);
+    InterTap nxt = inter_project(pool, plane, pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, dp_ok);
     for (int j = 0; j < n; j++) {
-        const PairConst* __restrict__ pc = pcs + j;
-        const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
-        float t0 = quot_with_rcp(row_dot_xp(pc->R + 0, xp0, xp1), depthp, dp, dp_ok) + pc->t[0];  // PM.cc:678
-        float t1 = quot_with_rcp(row_dot_xp(pc->R + 3, xp0, xp1), depthp, dp, dp_ok) + pc->t[1];
-        float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-        float t2 = quot_with_rcp(rzxp, depthp, dp, dp_ok) + pc->t[2];
-        float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
-        float v = pc->nfy * t1 + pc->ncy * t2;
-        const float r2 = 1.0f / t2;
-        const bool t2_ok = quot_ok_divisor(t2);
-        float xj = quot_with_rcp(u, t2, r2, t2_ok), yj = quot_with_rcp(v, t2, r2, t2_ok);  // PM.cc:680
-        float denom2 = depthp * pc->t[2];
-        float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
-        if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) continue;  // PM.cc:695
-        int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
-        // four taps fetched together; order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
-        // each image row's two taps are adjacent float2's: one 16-byte (8-byte aligned) load per row
-        const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
-        const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
-        const float2 h[4] = {make_float2(ra.r0, ra.s0), make_float2(rb.r0, rb.s0), make_float2(ra.r1, ra.s1),
-                             make_float2(rb.r1, rb.s1)};
+        const InterTap cur = nxt;
+        if (j + 1 < n) nxt = inter_project(pool, plane, pcs + j + 1, W, colsm1, rowsm1, xp0, xp1, depthp, dp, dp_ok);
+        if (!cur.valid) continue;
+        const float2 h[4] = {make_float2(cur.ra.r0, cur.ra.s0), make_float2(cur.rb.r0, cur.rb.s0),
+                             make_float2(cur.ra.r1, cur.ra.s1), make_float2(cur.rb.r1, cur.rb.s1)};
         int nj = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if ((double)h[k].x > 0.000001 && tap_compatible(depthj, h[k].x, h[k].y)) {
+            if (gt_1em6(h[k].x) && tap_compatible(cur.depthj, h[k].x, h[k].y)) {
                 nj++;
-                float djn = 1 / h[k].x;  // PM.cc:777-783
+                float djn = rcp_exact(h[k].x);  // PM.cc:777-783
                 float d2sigma = djn * djn * h[k].y;
-                const float rd = 1.0f / d2sigma;  // J and r0 share the divisor d2sigma
+                const float rd = rcp_exact(d2sigma);  // J and r0 share the divisor d2sigma
                 const bool d_ok = quot_ok_divisor(d2sigma);
-                float J = quot_with_rcp(-rzxp, d2sigma, rd, d_ok);                          // PM.cc:782
-                float r0 = quot_with_rcp(djn - dp * rzxp - pc->t[2], d2sigma, rd, d_ok);   // PM.cc:783
+                float J = quot_with_rcp(-cur.rzxp, d2sigma, rd, d_ok);                          // PM.cc:782
+                float r0 = quot_with_rcp(djn - dp * cur.rzxp - cur.t2c, d2sigma, rd, d_ok);    // PM.cc:783
                 sum_Jr = sum_Jr + J * r0;
                 sum_JJ = sum_JJ + J * J;
             }
@@ -812,7 +836,7 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     }
     if (kf_count < lambdaN) return 0.0f;   // PM.cc:764
     float dpDelta = (-sum_Jr) / sum_JJ;    // PM.cc:788-791
-    return 1 / (dp + dpDelta);             // PM.cc:793
+    return rcp_exact(dp + dpDelta);        // PM.cc:793
 }
 
 // Generic form: any depth map (e.g. uploaded by the caller).  64x16 tiles, in-tile compaction of
@@ -838,7 +862,7 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict_
         float r = (x < W && y < H) ? cur[y * W + x].x : 0.f;
         outv[L] = r;
         bool inset = (x >= 2 && x < W - 2 && y >= 2 && y < H - 2);  // PM.cc:659-660
-        f[i] = inset && !((double)r < 0.000001);                      // PM.cc:662
+        f[i] = inset && !(lt_1em6(r));                      // PM.cc:662
     }
     const int nAct = block_compact(f, act, wsum);
     __syncthreads();
@@ -884,7 +908,7 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __rest
     const long long o = (long long)rc.slot * plane + y * W + x;
     const float depthp = pool[o].x;
     float out = depthp;  // PM.cc:662: skipped pixels keep their value
-    if (!((double)depthp < 0.000001))
+    if (!(lt_1em6(depthp)))
         out = inter_check_pixel(pool, plane, rc, pairs + (long long)ref * n, n, W, H, x, y, depthp, lambdaN);
     chk[o] = out;
 }
@@ -935,13 +959,13 @@ __global__ __launch_bounds__(BLOCK) void k_pointset(const float* __restrict__ sr
     mat3_vec(Rwc, tcw, Ow);
     float inv_d = src_base[((long long)slot * plane + idx) * sstride];
     float* o = xyz + ((long long)slot * plane + idx) * 3;
-    if ((double)inv_d < 0.000001) {  // PM.cc:345
+    if (lt_1em6(inv_d)) {  // PM.cc:345
         o[0] = 0.f;
         o[1] = 0.f;
         o[2] = 0.f;
         return;
     }
-    float Z = 1 / inv_d;
+    float Z = rcp_exact(inv_d);
     float X = Z * ((float)x - m.cx) / m.fx;
     float Y = Z * ((float)y - m.cy) / m.fy;
 #pragma unroll
@@ -975,13 +999,13 @@ __global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict
     const long long idx = (long long)rc.slot * plane + y * W + x;
     float inv_d = src_base[idx * sstride];
     float* o = xyz + idx * 3;
-    if ((double)inv_d < 0.000001) {  // PM.cc:345
+    if (lt_1em6(inv_d)) {  // PM.cc:345
         o[0] = 0.f;
         o[1] = 0.f;
         o[2] = 0.f;
         return;
     }
-    float Z = 1 / inv_d;
+    float Z = rcp_exact(inv_d);
     float X = Z * ((float)x - m.cx) / m.fx;
     float Y = Z * ((float)y - m.cy) / m.fy;
 #pragma unroll
@@ -1050,6 +1074,30 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_div(double d, double r, unsi
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(bad, cnt);
+}
+
+// which = 6: rcp_exact vs the plain division for ALL 2^32 float bit patterns.  bad = mismatches, aux = operands
+// that took the reciprocal path.
+__global__ __launch_bounds__(BLOCK) void k_selftest_rcp(unsigned long long* __restrict__ bad,
+                                                        unsigned long long* __restrict__ fast)
+{
+    unsigned long long cnt = 0, nf = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float b = __uint_as_float((unsigned)i);
+        const float got = rcp_exact(b), want = 1.0f / b;
+        if (!(__float_as_uint(got) == __float_as_uint(want) || (got != got && want != want))) cnt++;
+        const float ab = fabsf(b);
+        if ((ab >= 0x1p-125f) & (ab < 0x1p125f)) nf++;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        nf += __shfl_down(nf, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        atomicAdd(fast, nf);
+    }
 }
 
 // which = 1: chi_test_fast vs chi_test on pseudo-random operands concentrated around the 5.99

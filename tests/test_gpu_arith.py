@@ -56,3 +56,12 @@ def test_shared_divisor_quotient(pkg, gpu_ok):
     assert bad == 0
     assert tested >= 2 ** 33
     eng.close()
+
+
+def test_exact_reciprocal(pkg, gpu_ok):
+    """v_rcp_f32 + one FMA residual step == IEEE 1.0f/b for every float bit pattern (guards route the rest)"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, fast = eng.selftest(6)
+    assert bad == 0
+    assert fast == 2 * 250 * 2 ** 23  # every operand with 2^-125 <= |b| < 2^125 took the reciprocal path
+    eng.close()
