@@ -285,6 +285,7 @@ __device__ __forceinline__ float match_cost(float pe2, float ge2, const DevParam
 #define SDM_SCAN_UNROLL 4
 #endif
 constexpr int SCAN_UNROLL = SDM_SCAN_UNROLL;
+typedef float v4f __attribute__((ext_vector_type(4)));  // one 128-bit VGPR tuple
 
 struct SearchStats {
     unsigned long long searches, candidates, gate_pass;
@@ -353,6 +354,9 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     if (ang_pi_rot >= 360) ang_pi_rot -= 360;
     if (ang_pi_rot < 0) ang_pi_rot += 360;
 
+    // closed-form gates need d < 360 and the default thresholds; with other thresholds the limit is -Inf and
+    // every candidate takes the reference statement (a float limit keeps the test free of a uniform-bool VGPR)
+    const float gate_lim = prm.default_gates ? 360.0f : -__builtin_inff();
     float old_err = 1000000.0f;
     float best_pe = 0.f, best_ge = 0.f;
     int best_pixel = 0;
@@ -379,7 +383,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 #endif
     for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
-        float4 rs[SCAN_UNROLL];
+        v4f rs[SCAN_UNROLL];
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             int uj = u0 + k;
@@ -389,22 +393,22 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             unsigned off = (__umul24((unsigned)(int)yc, (unsigned)W) + (unsigned)uc) << 4;  // rows, W < 2^24
             yfs[k] = yf;
 #if SDM_ABLATE == 5
-            rs[k] = make_float4(20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u));
+            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
 #else
-            rs[k] = *reinterpret_cast<const float4*>(nbase + off);
+            rs[k] = *reinterpret_cast<const v4f*>(nbase + off);
 #endif
         }
         // keep each record one 16-byte gather issued here: without this hipcc splits the first record
         // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++)
-            asm volatile("" : "+v"(rs[k].x), "+v"(rs[k].y), "+v"(rs[k].z), "+v"(rs[k].w));
+            asm volatile("" : "+v"(rs[k]));
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             const int uj = u0 + k;
             if (STATS && uj <= hi) st->candidates++;
             const float yf = yfs[k];
-            const float4 r = rs[k];
+            const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
             if (!((uj <= hi) & (yf >= 1.0f) & (yf < hlim))) continue;  // PM.cc:408 + N3
             if (r.x < prm.lambdaG) continue;                            // PM.cc:411
 #if SDM_ABLATE == 4
@@ -414,7 +418,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             const float d2 = r.y - th_line;     // PM.cc:415-416
             const float d3 = r.y - ang_pi_rot;  // PM.cc:427
             bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
-            if (__builtin_expect(!(prm.default_gates && (d2 < 360.0f) & (d3 < 360.0f)), 0))
+            if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
                 fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
             if (fail) continue;  // PM.cc:421,431
             if (STATS) st->gate_pass++;
