@@ -59,11 +59,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    # SDM_BENCH_REHEARSE=1: every rank on GPU 0 with a gloo group and a host-staged exchange -- a dry run of the
+    # multi-rank control flow on a one-GPU box; its numbers are not measurements and the JSON says so
+    rehearse = os.environ.get("SDM_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[args.res]
     W, H, N = cam["W"], cam["H"], args.nbrs
@@ -104,24 +112,8 @@ def main():
         eng.synchronize()
         t_h2d = (time.perf_counter() - t0) / len(ks)
 
-    nb_of = dict(zip(own, nbrs))
-    boundary, interior = pl["boundary"], pl["interior"]
-
     def step():
-        if world > 1 and args.exchange == "halo" and boundary:
-            # boundary keyframes first; their maps travel to the adjacent ranks (point-to-point over
-            # xGMI) while the interior keyframes are reconstructed
-            eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
-            works = shard.exchange_halo_async(pool, pl)
-            if interior:
-                eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
-            shard.wait_all(works)
-        else:
-            eng.recon(own, nbrs, min_d, max_d)
-            if world > 1:
-                shard.allgather_depth(pool, pl["first"], pl["count"])
-        eng.inter_check(own, nbrs, commit=False)
-        eng.pointset(own, source=1)
+        shard.pipeline_step(eng, pool, pl, min_d, max_d, args.exchange)
 
     def barrier():
         if world > 1:
@@ -150,7 +142,7 @@ def main():
     timing = eng.get_timing(reset=True)
     eng.enable_timing(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -199,6 +191,8 @@ def main():
             "algorithmic_bytes_per_launch": k1_bytes,
         },
     }
+    if rehearse:
+        out["rehearsal"] = "all ranks on GPU 0, gloo, host-staged exchange: control-flow dry run, not a measurement"
     if stats:
         out["scan"] = {
             "searches": stats["searches"], "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),

@@ -83,21 +83,47 @@ def _runs(idx):
     return [tuple(r) for r in runs]
 
 
+def _staged(pool, group):
+    """True when the pool lives on a GPU but the process group is gloo, which has no device
+    point-to-point: the exchange is then staged through host memory.  This exists to rehearse the
+    multi-rank flow with several ranks on ONE GPU (tests/test_gpu_shard.py, bench.py with
+    SDM_BENCH_REHEARSE=1); production runs use RCCL ("nccl") and never take this path."""
+    return pool.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _StagedRecv:
+    def __init__(self, work, buf, dst):
+        self.work, self.buf, self.dst = work, buf, dst
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.buf)
+
+
 def exchange_halo_async(pool, pl, group=None):
     """Starts the point-to-point exchange of the boundary maps; returns a list of work handles
     (empty if there is nothing to exchange).  Contiguous runs of keyframes are sent/received as
     views of `pool` (zero copy).  Call wait_all() before K4."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return []
-    ops = []
+    staged = _staged(pool, group)
+    ops, recvs = [], []
     for peer in sorted(set(pl["send"]) | set(pl["recv"])):
         for a, b in _runs(pl["send"].get(peer, [])):
-            ops.append(dist.P2POp(dist.isend, pool[a:b], peer, group=group))
+            src = pool[a:b].cpu() if staged else pool[a:b]  # .cpu() waits for the producing kernels
+            ops.append(dist.P2POp(dist.isend, src, peer, group=group))
         for a, b in _runs(pl["recv"].get(peer, [])):
-            ops.append(dist.P2POp(dist.irecv, pool[a:b], peer, group=group))
+            dst = torch.empty(pool[a:b].shape, dtype=pool.dtype) if staged else pool[a:b]
+            recvs.append((len(ops), dst, pool[a:b]))
+            ops.append(dist.P2POp(dist.irecv, dst, peer, group=group))
     if not ops:
         return []
-    return dist.batch_isend_irecv(ops)
+    works = dist.batch_isend_irecv(ops)
+    if staged:  # gloo returns one handle per op
+        assert len(works) == len(ops)
+        for i, buf, dst in recvs:
+            works[i] = _StagedRecv(works[i], buf, dst)
+    return works
 
 
 def wait_all(works):
@@ -110,5 +136,35 @@ def allgather_depth(pool, first, count, group=None):
     After the call every rank holds every keyframe's {rho, sigma}."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    if _staged(pool, group):
+        host = torch.empty(pool.shape, dtype=pool.dtype)
+        dist.all_gather_into_tensor(host, pool[first:first + count].cpu(), group=group)
+        pool.copy_(host)
+        return
     mine = pool[first:first + count]
     dist.all_gather_into_tensor(pool, mine, group=group)
+
+
+def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None):
+    """One pass of the hot path over this rank's keyframe block (what bench.py times and the
+    multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
+    check (K4, snapshot form) -> point set (K5).
+
+    halo: boundary keyframes are reconstructed first; their maps travel to the adjacent ranks
+    (point-to-point over xGMI) while the interior keyframes are reconstructed."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    own, nbrs = pl["own"], pl["nbrs"]
+    nb_of = dict(zip(own, nbrs))
+    boundary, interior = pl["boundary"], pl["interior"]
+    if world > 1 and exchange == "halo" and boundary:
+        eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+        works = exchange_halo_async(pool, pl, group)
+        if interior:
+            eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
+        wait_all(works)
+    else:
+        eng.recon(own, nbrs, min_d, max_d)
+        if world > 1:
+            allgather_depth(pool, pl["first"], pl["count"], group)
+    eng.inter_check(own, nbrs, commit=False)
+    eng.pointset(own, source=1)
