@@ -102,3 +102,52 @@ def test_fuzz_whole_path(pkg, oracle, gpu_ok, mode, seed):
         assert_bit_equal(np.float32([got["rho"], got["sigma"], got["best_u"], got["best_v"]]),
                          np.float32([ref["rho"], ref["sigma"], ref["best_u"], ref["best_v"]]), "pixel search")
     eng.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_fuzz_hostile_planes(pkg, oracle, gpu_ok, seed):
+    """caller-supplied GradImg / GradTheta / I_stddev with NaN, Inf, negative, huge and out-of-range values
+    (the reference never validates them): gates, costs, fusion and the checks must still agree bit for bit"""
+    rng = np.random.default_rng(2000 + seed)
+    W, H, n_kf, n = 96, 64, 6, 5
+    case = make_case(rng, oracle, W, H, n_kf, "small")
+    bad_g = np.float32([np.nan, np.inf, -np.inf, -5.0, 1e30, 8.0, 7.9999995, 0.0, 3e38])
+    bad_t = np.float32([np.nan, np.inf, -np.inf, -10.0, 360.0, 725.5, 1e9, -1e9, 359.99997, -0.0, 1080.0, -720.25])
+    odd_istd = {1: [0.0, float("nan"), float("inf"), 1e-30][seed % 4], 4: -3.0}  # two of the six keyframes
+    eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
+    okf = []
+    for k in range(n_kf):
+        g, th, s = case["derived"][k]
+        g, th = g.copy(), th.copy()
+        m = rng.random((H, W)) < 0.04
+        g[m] = rng.choice(bad_g, int(m.sum()))
+        m = rng.random((H, W)) < 0.04
+        th[m] = rng.choice(bad_t, int(m.sum()))
+        # angles a little outside [0, 360) exercise the reference form of the wrap (d >= 360 / d < -360)
+        m = rng.random((H, W)) < 0.05
+        th[m] = th[m] + np.float32(360.0) * rng.integers(-2, 3, int(m.sum())).astype(np.float32)
+        sk = odd_istd.get(k, s)
+        eng.upload_keyframe(k, case["im"][k], g, th, sk, case["K"][k], case["Tcw"][k])
+        okf.append(oracle.keyframe(case["im"][k], g, th, sk, case["K"][k], case["Tcw"][k]))
+    refs = list(range(n_kf))
+    nbrs = [[j for j in range(n_kf) if j != k][:n] for k in refs]
+    rots = rng.uniform(-400, 400, (n_kf, n)).astype(np.float32)
+    rots[rng.random((n_kf, n)) < 0.7] = 0
+    rots[0, 0], rots[1, 1] = np.nan, np.inf
+    eng.recon(refs, nbrs, 0.2, 5.0, rot=rots)
+    rho, sig = {}, {}
+    for k in refs:
+        r, s, _ = oracle.semi_dense_recon(okf[k], [okf[j] for j in nbrs[k]], rots[k], 0.2, 5.0)
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, r, "hostile/%d rho kf %d" % (seed, k))
+        assert_bit_equal(gs, s, "hostile/%d sigma kf %d" % (seed, k))
+        rho[k], sig[k] = r, s
+    assert sum(int((rho[k] > 1e-6).sum()) for k in refs) > 200, "the case must still fuse something"
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    for k in refs:
+        c = oracle.inter_check(okf[k], rho[k], [okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                               [sig[j] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), c, "hostile/%d checked kf %d" % (seed, k))
+        assert_bit_equal(eng.download_pointset(k), oracle.pointset(okf[k], c), "hostile/%d xyz kf %d" % (seed, k))
+    eng.close()
