@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--nbrs", type=int, default=20, help="covisible neighbours per keyframe")
     ap.add_argument("--res", default="480p", choices=["480p", "720p", "1080p"])
     ap.add_argument("--disparity", type=float, default=2.6, help="adjacent-keyframe disparity (px): scan-length knob")
-    ap.add_argument("--cpu-kfs", type=int, default=12, help="keyframes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N>1 exchange of {rho,sigma} maps between K3 and K4 (shard.py)")
