@@ -1,6 +1,7 @@
 // adapters/orbslam_carv_adapter.h -- glue a maintainer of atlas-jj/ORB-SLAM-free-space-carving adds to call the
-// MI355X engine from the fork.  NOT COMPILED IN THIS REPOSITORY: it needs OpenCV and the fork's own headers
-// (KeyFrame.h, MapPoint.h), neither of which is available in the build image.  See INTEGRATION.md §2-§3.
+// MI355X engine from the fork.  It needs OpenCV and the fork's own headers (KeyFrame.h, MapPoint.h), neither of which
+// is available in the build image; here it is compiled and unit-tested only against test doubles of exactly the
+// members it touches (tests/cpp/mock_fork, tests/test_adapter.py).  See INTEGRATION.md §2-§3.
 //
 // It fills sdm::KeyFrame (include/sdm/ProbabilityMapping.h) -- exactly the members the reference's
 // ProbabilityMapping.cc reads from ORB_SLAM2::KeyFrame -- from the real keyframe plus the
