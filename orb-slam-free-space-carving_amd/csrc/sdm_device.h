@@ -169,17 +169,19 @@ __device__ __forceinline__ float row_dot_xp(const float* r, float xp0, float xp1
 //   .w = bits: im(y,x) | im(y+1,x) << 8
 // bilinear<T>(img, yf, uj) of PM.cc:40-59 at integer uj only ever touches rows floor(yf) and
 // floor(yf)+1 of column uj, which is exactly one record.
-__device__ __forceinline__ float rec_lerp_im(const float4& r, int y0, float yf)
+// y1f = (float)(y0 + 1), passed as floorf(yf) + 1.0f (the same value for 0 <= yf < 2^23; v_floor + v_add is
+// cheaper than the int round trip: conversions issue at half the rate of add/mul, tools/ubench/oprate.hip)
+__device__ __forceinline__ float rec_lerp_im(const float4& r, float y1f, float yf)
 {
     unsigned w = __float_as_uint(r.w);
-    float y0w = (float)(y0 + 1) - yf;
+    float y0w = y1f - yf;
     float y1w = 1.0f - y0w;
     float v0 = (float)(int)(w & 0xffu), v1 = (float)(int)((w >> 8) & 0xffu);
     return v0 * y0w + v1 * y1w;
 }
-__device__ __forceinline__ float rec_lerp_grad(const float4& r, int y0, float yf)
+__device__ __forceinline__ float rec_lerp_grad(const float4& r, float y1f, float yf)
 {
-    float y0w = (float)(y0 + 1) - yf;
+    float y0w = y1f - yf;
     float y1w = 1.0f - y0w;
     return r.x * y0w + r.z * y1w;
 }
@@ -381,16 +383,19 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     old_err = ab;
     best_pixel = lo + 2;
 #endif
-    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL) {
+    const unsigned W16 = (unsigned)W << 4;  // record pitch in bytes (< 2^24)
+    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
+    float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
+    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
         v4f rs[SCAN_UNROLL];
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             int uj = u0 + k;
-            float yf = -(ab * (float)uj + cb);  // PM.cc:407,433
+            float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
             float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim2);
-            int uc = min(uj, hi);
-            unsigned off = (__umul24((unsigned)(int)yc, (unsigned)W) + (unsigned)uc) << 4;  // rows, W < 2^24
+            unsigned uc16 = min(((unsigned)u0 << 4) + 16u * k, hi16);  // min(uj, hi) * 16
+            unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
             yfs[k] = yf;
 #if SDM_ABLATE == 5
             rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
@@ -426,9 +431,9 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
             continue;
 #endif
-            const int vj = (int)yf;
-            float pe = pixel - rec_lerp_im(r, vj, yf);    // PM.cc:433
-            float ge = grad1 - rec_lerp_grad(r, vj, yf);  // PM.cc:434
+            const float vj1 = floorf(yf) + 1.0f;             // (float)((int)yf + 1): yf is in [1, H-1) here
+            float pe = pixel - rec_lerp_im(r, vj1, yf);    // PM.cc:433
+            float ge = grad1 - rec_lerp_grad(r, vj1, yf);  // PM.cc:434
             float err = match_cost(pe * pe, ge * ge, prm);  // PM.cc:436
             if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
                 best_pixel = uj;
@@ -455,8 +460,9 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     int y0p = (int)fyp, y0m = (int)fym;
     float4 rp = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0p, (unsigned)W) + (unsigned)up) << 4));
     float4 rm = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0m, (unsigned)W) + (unsigned)um) << 4));
-    float g = (rec_lerp_im(rp, y0p, yfp) - rec_lerp_im(rm, y0m, yfm)) / 2;      // PM.cc:452
-    float q = (rec_lerp_grad(rp, y0p, yfp) - rec_lerp_grad(rm, y0m, yfm)) / 2;  // PM.cc:453
+    const float y1p = fyp + 1.0f, y1m = fym + 1.0f;
+    float g = (rec_lerp_im(rp, y1p, yfp) - rec_lerp_im(rm, y1m, yfm)) / 2;      // PM.cc:452
+    float q = (rec_lerp_grad(rp, y1p, yfp) - rec_lerp_grad(rm, y1m, yfm)) / 2;  // PM.cc:453
     const double inv_theta = prm.inv_theta;
     float gg = g * g;
     float denom = (float)((double)gg + inv_theta * (double)q * (double)q);  // PM.cc:455

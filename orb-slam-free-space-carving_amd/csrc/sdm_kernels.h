@@ -758,44 +758,97 @@ struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizon
     float r0, s0, r1, s1;
 };
 
-// One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764).  Quotients sharing a
-// divisor (the three /depthp, the two /t2, the two /d2sigma) use quot_with_rcp (sdm_device.h).
-// The loop is software-pipelined by one neighbour: the projection into neighbour j+1 and its two
-// 16-byte row loads are issued before the taps of neighbour j are evaluated, so two gathers per lane
-// are in flight while the taps are evaluated (measured neutral at 480p, ~1 % at 1080p).
-struct InterTap {
-    Row2 ra, rb;   // rows y0 and y0+1: {rho,sigma} at x0 and x0+1
-    float depthj;  // PM.cc:684-688
-    float rzxp, t2c;
-    bool valid;    // PM.cc:695
+// ---- One pixel of PM.cc:659-796: returns the new rho (0 = rejected, PM.cc:764) -------------------------------
+// K4 spends its time in instruction issue, and with per-quotient guards the SCALAR pipe (one per CU: every
+// exec-mask region and lane-mask operation goes through it, tools/ubench/salu.hip) was the longer pole: ~240
+// scalar instructions per pixel-neighbour against ~330 vector ones.  So the per-neighbour body is straight-line:
+//   * every quotient takes its reciprocal form unconditionally (Markstein: q = a*r, two FMA residual steps; 1/b as
+//     v_rcp_f32 + one FMA step) -- bit-identical to the IEEE quotient whenever numerator and divisor magnitudes lie
+//     in [2^-40, 2^41) and the divisor's significand is not all ones (sdm_selftest(5)/(6));
+//   * instead of guarding each quotient, the running min/max of the operand magnitudes (as integers, so NaN and
+//     Inf land above the window) and an all-ones detector are folded in with v_min3/v_max3;
+//   * the four taps are predicated (operands of a tap that does not count are replaced by 1.0f, its terms are not
+//     added), and a tap whose approximate statistic is within 2^-12 of 3.84, or whose sigma is unsafe, raises the
+//     same flag;
+//   * ONE test per neighbour: lanes whose flag is set redo that neighbour with the reference statement (plain
+//     divisions, the double tap test).
+struct K4Guard {
+    unsigned hi, lo, ones;  // max / min of |operand| bit patterns; min over divisors of ((bits | ~mant) + 1): 0 = all ones
 };
-__device__ __forceinline__ InterTap inter_project(const float2* __restrict__ pool, long long plane,
-                                                  const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1,
-                                                  float xp0, float xp1, float depthp, float dp, bool dp_ok)
+constexpr unsigned K4_MAG_LO = 87u << 23;          // 2^-40
+constexpr unsigned K4_MAG_HI = (168u << 23) - 1u;  // just below 2^41
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
+__device__ __forceinline__ void guard2(K4Guard& g, float a, float b)
 {
-    InterTap o;
-    const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
-    float t0 = quot_with_rcp(row_dot_xp(pc->R + 0, xp0, xp1), depthp, dp, dp_ok) + pc->t[0];  // PM.cc:678
-    float t1 = quot_with_rcp(row_dot_xp(pc->R + 3, xp0, xp1), depthp, dp, dp_ok) + pc->t[1];
+    const unsigned ua = absbits(a), ub = absbits(b);
+    g.hi = umax3(g.hi, ua, ub);
+    g.lo = umin3(g.lo, ua, ub);
+}
+__device__ __forceinline__ void guard_divisor(K4Guard& g, float b)
+{
+    g.ones = min(g.ones, (__float_as_uint(b) | 0xFF800000u) + 1u);
+}
+__device__ __forceinline__ float rcp_fast(float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float quot_fast(float a, float b, float r)
+{
+    float q0 = a * r;
+    float e0 = __builtin_fmaf(-q0, b, a);
+    float q1 = __builtin_fmaf(e0, r, q0);
+    float e1 = __builtin_fmaf(-q1, b, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+
+// the reference statement for one neighbour (PM.cc:677-755, 777-783), given the rows already fetched when the
+// projection agreed (ra/rb are re-read here because an inexact fast projection may have addressed another pixel)
+struct K4Sums {
+    int kf_count;
+    float sum_Jr, sum_JJ;
+};
+__device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ nb, const PairConst* __restrict__ pc,
+                                                     int W, float colsm1, float rowsm1, float xp0, float xp1,
+                                                     float depthp, float dp, K4Sums in)
+{
+    int kf_count = in.kf_count;
+    float sum_Jr = in.sum_Jr, sum_JJ = in.sum_JJ;
+    float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
+    float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
     float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-    float t2 = quot_with_rcp(rzxp, depthp, dp, dp_ok) + pc->t[2];
+    float t2 = rzxp / depthp + pc->t[2];
     float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
     float v = pc->nfy * t1 + pc->ncy * t2;
-    const float r2 = rcp_exact(t2);
-    const bool t2_ok = quot_ok_divisor(t2);
-    float xj = quot_with_rcp(u, t2, r2, t2_ok), yj = quot_with_rcp(v, t2, r2, t2_ok);  // PM.cc:680
+    float xj = u / t2, yj = v / t2;  // PM.cc:680
     float denom2 = depthp * pc->t[2];
-    o.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
-    o.rzxp = rzxp;
-    o.t2c = pc->t[2];
-    o.valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
-    // invalid lanes fetch pixel (0,0): the loads stay unconditional, the result is ignored
-    const int x0 = o.valid ? (int)floorf(xj) : 0, y0 = o.valid ? (int)floorf(yj) : 0;
-    // four taps fetched together; order (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
-    // each image row's two taps are adjacent float2's: one 16-byte (8-byte aligned) load per row
-    o.ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
-    o.rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
-    return o;
+    float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) return in;  // PM.cc:695
+    int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
+    const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
+    const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+    const float2 h[4] = {make_float2(ra.r0, ra.s0), make_float2(rb.r0, rb.s0), make_float2(ra.r1, ra.s1),
+                         make_float2(rb.r1, rb.s1)};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+    int nj = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!gt_1em6(h[k].x)) continue;
+        float dd = depthj - h[k].x;
+        float test = (float)(((double)dd * (double)dd) / ((double)h[k].y * (double)h[k].y));  // PM.cc:709
+        if (!((double)test < 3.84)) continue;
+        nj++;
+        float djn = 1 / h[k].x;  // PM.cc:777-783
+        float d2sigma = djn * djn * h[k].y;
+        float J = (-rzxp) / d2sigma;                          // PM.cc:782
+        float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;    // PM.cc:783
+        sum_Jr = sum_Jr + J * r0;
+        sum_JJ = sum_JJ + J * J;
+    }
+    if (nj >= 1) kf_count++;  // PM.cc:755
+    return K4Sums{kf_count, sum_Jr, sum_JJ};
 }
 
 __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
@@ -806,33 +859,82 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     const float colsm1 = (float)(W - 1), rowsm1 = (float)(H - 1);
     const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
     const float dp = rcp_exact(depthp);                                                 // PM.cc:769
-    const bool dp_ok = quot_ok_divisor(depthp);
+    // depthp is a divisor of every neighbour's three quotients: its checks are loop invariant
+    K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
+    guard_divisor(g0, depthp);
     int kf_count = 0;
     float sum_Jr = 0.f, sum_JJ = 0.f;
-    if (n <= 0) return (0 < lambdaN) ? 0.0f : rcp_exact(dp + (-sum_Jr) / sum_JJ);
-    InterTap nxt = inter_project(pool, plane, pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, dp_ok);
+    const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
     for (int j = 0; j < n; j++) {
-        const InterTap cur = nxt;
-        if (j + 1 < n) nxt = inter_project(pool, plane, pcs + j + 1, W, colsm1, rowsm1, xp0, xp1, depthp, dp, dp_ok);
-        if (!cur.valid) continue;
-        const float2 h[4] = {make_float2(cur.ra.r0, cur.ra.s0), make_float2(cur.rb.r0, cur.rb.s0),
-                             make_float2(cur.ra.r1, cur.ra.s1), make_float2(cur.rb.r1, cur.rb.s1)};
+        const PairConst* __restrict__ pc = pcs + j;
+        const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
+        K4Guard g = g0;
+        const float n0 = row_dot_xp(pc->R + 0, xp0, xp1), n1 = row_dot_xp(pc->R + 3, xp0, xp1);
+        const float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+        guard2(g, n0, n1);
+        const float t0 = quot_fast(n0, depthp, dp) + pc->t[0];  // PM.cc:678
+        const float t1 = quot_fast(n1, depthp, dp) + pc->t[1];
+        const float t2 = quot_fast(rzxp, depthp, dp) + pc->t[2];
+        guard2(g, rzxp, t2);
+        guard_divisor(g, t2);
+        const float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
+        const float v = pc->nfy * t1 + pc->ncy * t2;
+        guard2(g, u, v);
+        const float r2 = rcp_fast(t2);
+        const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
+        const float denom2 = depthp * pc->t[2];
+        const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+        const bool valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
+        // lanes that project outside fetch pixel (0,0): the loads stay unconditional, their taps never count
+        const int x0 = valid ? (int)floorf(xj) : 0, y0 = valid ? (int)floorf(yj) : 0;
+        const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
+        const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+        const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+        const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
+        const float lim = valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
+        float nsJr = sum_Jr, nsJJ = sum_JJ;
         int nj = 0;
+        unsigned amb = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (gt_1em6(h[k].x) && tap_compatible(cur.depthj, h[k].x, h[k].y)) {
-                nj++;
-                float djn = rcp_exact(h[k].x);  // PM.cc:777-783
-                float d2sigma = djn * djn * h[k].y;
-                const float rd = rcp_exact(d2sigma);  // J and r0 share the divisor d2sigma
-                const bool d_ok = quot_ok_divisor(d2sigma);
-                float J = quot_with_rcp(-cur.rzxp, d2sigma, rd, d_ok);                          // PM.cc:782
-                float r0 = quot_with_rcp(djn - dp * cur.rzxp - cur.t2c, d2sigma, rd, d_ok);    // PM.cc:783
-                sum_Jr = sum_Jr + J * r0;
-                sum_JJ = sum_JJ + J * J;
-            }
+            // tap_compatible's prefilter: approx = dd^2 / sigma^2 from a 1-ulp reciprocal; unsafe sigma -> NaN
+            const float dd = depthj - hr[k];
+            const float s2 = hs[k] * hs[k];
+            const float rs = (__builtin_amdgcn_fmed3f(s2, 1.0e-30f, 1.0e30f) == s2) ? __builtin_amdgcn_rcpf(s2)
+                                                                                      : __builtin_nanf("");
+            float approx = (dd * dd) * rs;
+            approx = (hr[k] > lim) ? approx : __builtin_inff();   // not a candidate tap: never compatible, never ambiguous
+            const bool c = approx < 3.8397f;
+            amb |= !(fabsf(approx - 3.84f) > 0.00032f) ? 1u : 0u;  // inside the band, or NaN: the exact test decides
+            // operands of a tap that does not count are made harmless
+            const float hx = c ? hr[k] : 1.0f, sg = c ? hs[k] : 1.0f;
+            const float djn = rcp_fast(hx);  // PM.cc:777-783
+            const float d2sigma = djn * djn * sg;
+            const float rd = rcp_fast(d2sigma);
+            const float J = quot_fast(-rzxp, d2sigma, rd);  // PM.cc:782
+            float rnum = djn - dp * rzxp - pc->t[2];        // PM.cc:783
+            rnum = c ? rnum : 1.0f;
+            const float r0 = quot_fast(rnum, d2sigma, rd);
+            guard2(g, hx, d2sigma);
+            guard2(g, rnum, rnum);
+            guard_divisor(g, d2sigma);
+            const float aJr = nsJr + J * r0, aJJ = nsJJ + J * J;
+            nsJr = c ? aJr : nsJr;
+            nsJJ = c ? aJJ : nsJJ;
+            nj += c ? 1 : 0;
         }
-        if (nj >= 1) kf_count++;  // PM.cc:755
+        const bool slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u);
+        if (__builtin_expect(slow, 0)) {
+            const K4Sums o = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp,
+                                                   K4Sums{kf_count, sum_Jr, sum_JJ});
+            kf_count = o.kf_count;
+            sum_Jr = o.sum_Jr;
+            sum_JJ = o.sum_JJ;
+        } else {
+            sum_Jr = nsJr;
+            sum_JJ = nsJJ;
+            kf_count += (nj >= 1) ? 1 : 0;  // PM.cc:755
+        }
     }
     if (kf_count < lambdaN) return 0.0f;   // PM.cc:764
     float dpDelta = (-sum_Jr) / sum_JJ;    // PM.cc:788-791
