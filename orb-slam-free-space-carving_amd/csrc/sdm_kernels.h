@@ -741,19 +741,6 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
 }
 
 // ---- K4: InterKeyFrameDepthChecking, PM.cc:628-799 ------------------------------------------------------
-// The "test < 3.84" decision of PM.cc:709-710 (a double division per tap) is pre-filtered with a
-// float reciprocal exactly like ChiTest (sdm_device.h): only results inside the band
-// 3.84*(1 +- 2^-14), or unsafe sigmas, take the exact double path.
-__device__ __forceinline__ bool tap_compatible(float depthj, float d, float sg)
-{
-    float dd = depthj - d;
-    float approx = (dd * dd) * safe_rcp_sq(sg);
-    if (approx < 3.8397f) return true;
-    if (approx > 3.8403f) return false;
-    float test = (float)(((double)dd * (double)dd) / ((double)sg * (double)sg));  // PM.cc:709
-    return (double)test < 3.84;
-}
-
 struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizontally adjacent pixels
     float r0, s0, r1, s1;
 };
@@ -768,8 +755,8 @@ struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizon
 //   * instead of guarding each quotient, the running min/max of the operand magnitudes (as integers, so NaN and
 //     Inf land above the window) and an all-ones detector are folded in with v_min3/v_max3;
 //   * the four taps are predicated (operands of a tap that does not count are replaced by 1.0f, its terms are not
-//     added), and a tap whose approximate statistic is within 2^-12 of 3.84, or whose sigma is unsafe, raises the
-//     same flag;
+//     added); the 3.84 test is two multiplications and two comparisons, and a tap whose statistic is within
+//     2^-13 of 3.84, or whose rho/sigma leave [2^-13, 2^13), raises the same flag;
 //   * ONE test per neighbour: lanes whose flag is set redo that neighbour with the reference statement (plain
 //     divisions, the double tap test).
 struct K4Guard {
@@ -777,6 +764,8 @@ struct K4Guard {
 };
 constexpr unsigned K4_MAG_LO = 87u << 23;          // 2^-40
 constexpr unsigned K4_MAG_HI = (168u << 23) - 1u;  // just below 2^41
+constexpr unsigned K4_TAP_LO = 114u << 23;          // 2^-13
+constexpr unsigned K4_TAP_HI = (140u << 23) - 1u;  // just below 2^13
 __device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
 __device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
@@ -895,19 +884,27 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
         float nsJr = sum_Jr, nsJJ = sum_JJ;
         int nj = 0;
         unsigned amb = 0;
+        // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
+        // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator and the
+        // all-ones significand of d2sigma are tracked besides.
+        unsigned t_hi = K4_TAP_LO, t_lo = K4_TAP_LO;
+        float rn[4], d2s[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // tap_compatible's prefilter: approx = dd^2 / sigma^2 from a 1-ulp reciprocal; unsafe sigma -> NaN
+            const bool cand = hr[k] > lim;
+            const float hx = cand ? hr[k] : 1.0f, sg = cand ? hs[k] : 1.0f;  // harmless operands otherwise
+            const unsigned uh = absbits(hx), us = absbits(sg);
+            t_hi = umax3(t_hi, uh, us);
+            t_lo = umin3(t_lo, uh, us);
+            // "test < 3.84" (PM.cc:709-710) without a division: with sigma in the window, dd^2 < 3.8397 sigma^2 and
+            // dd^2 > 3.8403 sigma^2 (float products, relative error < 2^-22) are certain; in between the exact test
+            // decides.  dd^2 = +Inf marks a tap that is not a candidate: never compatible, never ambiguous.
             const float dd = depthj - hr[k];
-            const float s2 = hs[k] * hs[k];
-            const float rs = (__builtin_amdgcn_fmed3f(s2, 1.0e-30f, 1.0e30f) == s2) ? __builtin_amdgcn_rcpf(s2)
-                                                                                      : __builtin_nanf("");
-            float approx = (dd * dd) * rs;
-            approx = (hr[k] > lim) ? approx : __builtin_inff();   // not a candidate tap: never compatible, never ambiguous
-            const bool c = approx < 3.8397f;
-            amb |= !(fabsf(approx - 3.84f) > 0.00032f) ? 1u : 0u;  // inside the band, or NaN: the exact test decides
-            // operands of a tap that does not count are made harmless
-            const float hx = c ? hr[k] : 1.0f, sg = c ? hs[k] : 1.0f;
+            const float dd2 = cand ? dd * dd : __builtin_inff();
+            const float s2 = sg * sg;
+            const bool c = dd2 < 3.8397f * s2;
+            const bool sure_no = dd2 > 3.8403f * s2;
+            amb |= c ? 0u : (sure_no ? 0u : 1u);  // also NaN operands
             const float djn = rcp_fast(hx);  // PM.cc:777-783
             const float d2sigma = djn * djn * sg;
             const float rd = rcp_fast(d2sigma);
@@ -915,15 +912,19 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
             float rnum = djn - dp * rzxp - pc->t[2];        // PM.cc:783
             rnum = c ? rnum : 1.0f;
             const float r0 = quot_fast(rnum, d2sigma, rd);
-            guard2(g, hx, d2sigma);
-            guard2(g, rnum, rnum);
-            guard_divisor(g, d2sigma);
+            rn[k] = rnum;
+            d2s[k] = d2sigma;
             const float aJr = nsJr + J * r0, aJJ = nsJJ + J * J;
             nsJr = c ? aJr : nsJr;
             nsJJ = c ? aJJ : nsJJ;
             nj += c ? 1 : 0;
         }
-        const bool slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u);
+        guard2(g, rn[0], rn[1]);
+        guard2(g, rn[2], rn[3]);
+        g.ones = umin3(g.ones, (__float_as_uint(d2s[0]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[1]) | 0xFF800000u) + 1u);
+        g.ones = umin3(g.ones, (__float_as_uint(d2s[2]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[3]) | 0xFF800000u) + 1u);
+        const bool slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u) | (t_lo < K4_TAP_LO) |
+                          (t_hi > K4_TAP_HI);
         if (__builtin_expect(slow, 0)) {
             const K4Sums o = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp,
                                                    K4Sums{kf_count, sum_Jr, sum_JJ});

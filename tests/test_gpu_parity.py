@@ -511,3 +511,46 @@ def test_error_behaviour(pkg, gpu_ok):
         eng.download_checked(0)
     assert e.value.code == 4
     eng.close()
+
+
+def test_inter_check_threshold_sweep(pkg, oracle, gpu_ok):
+    """the 3.84 tap test (PM.cc:709-710) swept through its threshold with ulp-dense sigma values: coincident
+    cameras make every pixel project onto itself, rho_j is constant, so each neighbour tap's statistic is
+    (1 - 0.98)^2 / sigma^2 with sigma stepping by one part in 2^25 around the critical value; also sigma / rho
+    outside the kernel's fast window (tiny, huge, zero, Inf, NaN).  Every decision must match the oracle."""
+    W, H, n_kf, n = 320, 96, 4, 3
+    rng = np.random.default_rng(77)
+    K = np.float32([300.0, 300.0, 159.5, 47.5])
+    Tcw = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1).astype(np.float32)
+    eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
+    okf = []
+    for k in range(n_kf):
+        im = rng.integers(0, 256, (H, W)).astype(np.uint8)
+        eng.upload_image(k, im, K, Tcw)
+        g, th, s = oracle.gradient_prepass(im)
+        okf.append(oracle.keyframe(im, g, th, s, K, Tcw))
+    dd = float(np.float32(1.0) - np.float32(0.98))
+    s_thr = dd / np.sqrt(3.84)
+    idx = np.arange(W * H, dtype=np.float64).reshape(H, W)
+    rho, sig = {}, {}
+    rho[0] = np.full((H, W), 1.0, np.float32)
+    sig[0] = np.full((H, W), 0.01, np.float32)
+    for k in range(1, n_kf):
+        rho[k] = np.full((H, W), 0.98, np.float32)
+        off = (k - 2) * 1000.0  # each neighbour crosses the threshold at another pixel
+        sig[k] = (s_thr * (1.0 + (idx - W * H / 2 + off) * 2.0 ** -25)).astype(np.float32)
+        # rows of odd operands: outside the fast window or degenerate; the reference must still be matched
+        odd = np.float32([1e-5, 3e-5, 1.3e-4, 9000.0, 0.0, np.inf, np.nan, 1e-20, 1e20, -0.01])
+        sig[k][5 + k, :] = np.resize(odd, W)
+        rho[k][9 + k, :] = np.resize(np.float32([2e-6, 1e-4, 1.3e-4, 8000.0, 9000.0, 1e9, np.inf, np.nan, 0.98, 1.0]), W)
+    for k in range(n_kf):
+        eng.upload_depth(k, rho[k], sig[k])
+    refs, nbrs = [0], [[1, 2, 3]]
+    eng.inter_check(refs, nbrs)
+    ref = oracle.inter_check(okf[0], rho[0], [okf[j] for j in nbrs[0]], [rho[j] for j in nbrs[0]],
+                             [sig[j] for j in nbrs[0]])
+    got = eng.download_checked(0)
+    assert_bit_equal(got, ref, "threshold sweep")
+    kept = int((ref > 1e-6).sum())
+    assert 0.2 * W * H < kept < 0.8 * W * H, kept  # the sweep really straddles the threshold
+    eng.close()
