@@ -1155,6 +1155,26 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     } else if (which == 5) {
         hipLaunchKernelGGL(k_selftest_quot, dim3(4096), dim3(BLOCK), 0, c->stream, 8192, c->d_stats + 5,
                            c->d_stats + 6);
+    } else if (which == 7) {
+        // scratch: one 3x2 {rho,sigma} patch and one constant block per thread
+        const int blocks = 1024;
+        float2* d_patch = nullptr;
+        PairConst* d_pc = nullptr;
+        HIP_TRY(hipMalloc(&d_patch, sizeof(float2) * 6 * blocks * BLOCK));
+        if (hipMalloc(&d_pc, sizeof(PairConst) * blocks * BLOCK) != hipSuccess) {
+            (void)hipFree(d_patch);
+            return fail(SDM_EHIP, "selftest scratch allocation failed");
+        }
+        hipLaunchKernelGGL(k_selftest_k4, dim3(blocks), dim3(BLOCK), 0, c->stream, 2048, d_patch, d_pc, c->d_stats + 5,
+                           c->d_stats + 6);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_stats + 5, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_patch);
+        (void)hipFree(d_pc);
+        if (e != hipSuccess) return fail(SDM_EHIP, hipGetErrorString(e));
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+        return SDM_OK;
     } else if (which == 6) {
         hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else if (which == 3) {

@@ -840,6 +840,84 @@ __device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ 
     return K4Sums{kf_count, sum_Jr, sum_JJ};
 }
 
+// the straight-line form for one neighbour; *slow is set for lanes whose result must not be used
+__device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict__ nb, const PairConst* __restrict__ pc,
+                                                       int W, float colsm1, float rowsm1, float xp0, float xp1,
+                                                       float depthp, float dp, const K4Guard& g0, K4Sums in,
+                                                       bool* slow)
+{
+    const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
+    K4Guard g = g0;
+    const float n0 = row_dot_xp(pc->R + 0, xp0, xp1), n1 = row_dot_xp(pc->R + 3, xp0, xp1);
+    const float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+    guard2(g, n0, n1);
+    const float t0 = quot_fast(n0, depthp, dp) + pc->t[0];  // PM.cc:678
+    const float t1 = quot_fast(n1, depthp, dp) + pc->t[1];
+    const float t2 = quot_fast(rzxp, depthp, dp) + pc->t[2];
+    guard2(g, rzxp, t2);
+    guard_divisor(g, t2);
+    const float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
+    const float v = pc->nfy * t1 + pc->ncy * t2;
+    guard2(g, u, v);
+    const float r2 = rcp_fast(t2);
+    const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
+    const float denom2 = depthp * pc->t[2];
+    const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    const bool valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
+    // lanes that project outside fetch pixel (0,0): the loads stay unconditional, their taps never count
+    const int x0 = valid ? (int)floorf(xj) : 0, y0 = valid ? (int)floorf(yj) : 0;
+    const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
+    const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+    const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
+    const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
+    const float lim = valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
+    float nsJr = in.sum_Jr, nsJJ = in.sum_JJ;
+    int nj = 0;
+    unsigned amb = 0;
+    // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
+    // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator and the
+    // all-ones significand of d2sigma are tracked besides.
+    unsigned t_hi = K4_TAP_LO, t_lo = K4_TAP_LO;
+    float rn[4], d2s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool cand = hr[k] > lim;
+        const float hx = cand ? hr[k] : 1.0f, sg = cand ? hs[k] : 1.0f;  // harmless operands otherwise
+        const unsigned uh = absbits(hx), us = absbits(sg);
+        t_hi = umax3(t_hi, uh, us);
+        t_lo = umin3(t_lo, uh, us);
+        // "test < 3.84" (PM.cc:709-710) without a division: with sigma in the window, dd^2 < 3.8397 sigma^2 and
+        // dd^2 > 3.8403 sigma^2 (float products, relative error < 2^-22) are certain; in between the exact test
+        // decides.  dd^2 = +Inf marks a tap that is not a candidate: never compatible, never ambiguous.
+        const float dd = depthj - hr[k];
+        const float dd2 = cand ? dd * dd : __builtin_inff();
+        const float s2 = sg * sg;
+        const bool c = dd2 < 3.8397f * s2;
+        const bool sure_no = dd2 > 3.8403f * s2;
+        amb |= c ? 0u : (sure_no ? 0u : 1u);  // also NaN operands
+        const float djn = rcp_fast(hx);  // PM.cc:777-783
+        const float d2sigma = djn * djn * sg;
+        const float rd = rcp_fast(d2sigma);
+        const float J = quot_fast(-rzxp, d2sigma, rd);  // PM.cc:782
+        float rnum = djn - dp * rzxp - pc->t[2];        // PM.cc:783
+        rnum = c ? rnum : 1.0f;
+        const float r0 = quot_fast(rnum, d2sigma, rd);
+        rn[k] = rnum;
+        d2s[k] = d2sigma;
+        const float aJr = nsJr + J * r0, aJJ = nsJJ + J * J;
+        nsJr = c ? aJr : nsJr;
+        nsJJ = c ? aJJ : nsJJ;
+        nj += c ? 1 : 0;
+    }
+    guard2(g, rn[0], rn[1]);
+    guard2(g, rn[2], rn[3]);
+    g.ones = umin3(g.ones, (__float_as_uint(d2s[0]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[1]) | 0xFF800000u) + 1u);
+    g.ones = umin3(g.ones, (__float_as_uint(d2s[2]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[3]) | 0xFF800000u) + 1u);
+    *slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u) | (t_lo < K4_TAP_LO) |
+            (t_hi > K4_TAP_HI);
+    return K4Sums{in.kf_count + ((nj >= 1) ? 1 : 0), nsJr, nsJJ};  // PM.cc:755
+}
+
 __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
                                                    long long plane, const RefConst& rc,
                                                    const PairConst* __restrict__ pcs, int n, int W, int H, int x,
@@ -851,95 +929,20 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     // depthp is a divisor of every neighbour's three quotients: its checks are loop invariant
     K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
     guard_divisor(g0, depthp);
-    int kf_count = 0;
-    float sum_Jr = 0.f, sum_JJ = 0.f;
-    const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
+    K4Sums acc = {0, 0.f, 0.f};
     for (int j = 0; j < n; j++) {
         const PairConst* __restrict__ pc = pcs + j;
         const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
-        K4Guard g = g0;
-        const float n0 = row_dot_xp(pc->R + 0, xp0, xp1), n1 = row_dot_xp(pc->R + 3, xp0, xp1);
-        const float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-        guard2(g, n0, n1);
-        const float t0 = quot_fast(n0, depthp, dp) + pc->t[0];  // PM.cc:678
-        const float t1 = quot_fast(n1, depthp, dp) + pc->t[1];
-        const float t2 = quot_fast(rzxp, depthp, dp) + pc->t[2];
-        guard2(g, rzxp, t2);
-        guard_divisor(g, t2);
-        const float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
-        const float v = pc->nfy * t1 + pc->ncy * t2;
-        guard2(g, u, v);
-        const float r2 = rcp_fast(t2);
-        const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
-        const float denom2 = depthp * pc->t[2];
-        const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
-        const bool valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
-        // lanes that project outside fetch pixel (0,0): the loads stay unconditional, their taps never count
-        const int x0 = valid ? (int)floorf(xj) : 0, y0 = valid ? (int)floorf(yj) : 0;
-        const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
-        const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
-        const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
-        const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
-        const float lim = valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
-        float nsJr = sum_Jr, nsJJ = sum_JJ;
-        int nj = 0;
-        unsigned amb = 0;
-        // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
-        // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator and the
-        // all-ones significand of d2sigma are tracked besides.
-        unsigned t_hi = K4_TAP_LO, t_lo = K4_TAP_LO;
-        float rn[4], d2s[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool cand = hr[k] > lim;
-            const float hx = cand ? hr[k] : 1.0f, sg = cand ? hs[k] : 1.0f;  // harmless operands otherwise
-            const unsigned uh = absbits(hx), us = absbits(sg);
-            t_hi = umax3(t_hi, uh, us);
-            t_lo = umin3(t_lo, uh, us);
-            // "test < 3.84" (PM.cc:709-710) without a division: with sigma in the window, dd^2 < 3.8397 sigma^2 and
-            // dd^2 > 3.8403 sigma^2 (float products, relative error < 2^-22) are certain; in between the exact test
-            // decides.  dd^2 = +Inf marks a tap that is not a candidate: never compatible, never ambiguous.
-            const float dd = depthj - hr[k];
-            const float dd2 = cand ? dd * dd : __builtin_inff();
-            const float s2 = sg * sg;
-            const bool c = dd2 < 3.8397f * s2;
-            const bool sure_no = dd2 > 3.8403f * s2;
-            amb |= c ? 0u : (sure_no ? 0u : 1u);  // also NaN operands
-            const float djn = rcp_fast(hx);  // PM.cc:777-783
-            const float d2sigma = djn * djn * sg;
-            const float rd = rcp_fast(d2sigma);
-            const float J = quot_fast(-rzxp, d2sigma, rd);  // PM.cc:782
-            float rnum = djn - dp * rzxp - pc->t[2];        // PM.cc:783
-            rnum = c ? rnum : 1.0f;
-            const float r0 = quot_fast(rnum, d2sigma, rd);
-            rn[k] = rnum;
-            d2s[k] = d2sigma;
-            const float aJr = nsJr + J * r0, aJJ = nsJJ + J * J;
-            nsJr = c ? aJr : nsJr;
-            nsJJ = c ? aJJ : nsJJ;
-            nj += c ? 1 : 0;
-        }
-        guard2(g, rn[0], rn[1]);
-        guard2(g, rn[2], rn[3]);
-        g.ones = umin3(g.ones, (__float_as_uint(d2s[0]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[1]) | 0xFF800000u) + 1u);
-        g.ones = umin3(g.ones, (__float_as_uint(d2s[2]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[3]) | 0xFF800000u) + 1u);
-        const bool slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u) | (t_lo < K4_TAP_LO) |
-                          (t_hi > K4_TAP_HI);
-        if (__builtin_expect(slow, 0)) {
-            const K4Sums o = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp,
-                                                   K4Sums{kf_count, sum_Jr, sum_JJ});
-            kf_count = o.kf_count;
-            sum_Jr = o.sum_Jr;
-            sum_JJ = o.sum_JJ;
-        } else {
-            sum_Jr = nsJr;
-            sum_JJ = nsJJ;
-            kf_count += (nj >= 1) ? 1 : 0;  // PM.cc:755
-        }
+        bool slow;
+        const K4Sums fast = inter_neighbour_fast(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0, acc, &slow);
+        if (__builtin_expect(slow, 0))
+            acc = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, acc);
+        else
+            acc = fast;
     }
-    if (kf_count < lambdaN) return 0.0f;   // PM.cc:764
-    float dpDelta = (-sum_Jr) / sum_JJ;    // PM.cc:788-791
-    return rcp_exact(dp + dpDelta);        // PM.cc:793
+    if (acc.kf_count < lambdaN) return 0.0f;      // PM.cc:764
+    float dpDelta = (-acc.sum_Jr) / acc.sum_JJ;   // PM.cc:788-791
+    return rcp_exact(dp + dpDelta);               // PM.cc:793
 }
 
 // Generic form: any depth map (e.g. uploaded by the caller).  64x16 tiles, in-tile compaction of
@@ -1212,6 +1215,87 @@ __device__ __forceinline__ unsigned xs32(unsigned& s)
     s ^= s << 5;
     return s;
 }
+
+// which = 7: K4's straight-line per-neighbour body vs the reference statement on random geometry and 2x2 depth
+// patches (log-uniform magnitudes far beyond the fast windows, tap statistics concentrated on the 3.84 threshold,
+// zero / Inf / NaN operands).  bad = lanes whose fast result was accepted (slow flag clear) but differs from the
+// exact one; aux = lanes that were accepted.
+__device__ __forceinline__ float st_uniform(unsigned& s) { return (xs32(s) >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float st_logmag(unsigned& s, float lo_exp, float hi_exp)
+{
+    return exp2f(lo_exp + (hi_exp - lo_exp) * st_uniform(s));
+}
+__global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __restrict__ patches,
+                                                       PairConst* __restrict__ pcs, unsigned long long* __restrict__ bad,
+                                                       unsigned long long* __restrict__ accepted)
+{
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned s = 0x9E3779B9u * (gid + 1);
+    float2* nb = patches + (long long)gid * 6;  // a private 3x2 map (W = 3): rows y0, y0+1 at x0 = 0 or 1
+    PairConst* pc = pcs + gid;
+    unsigned long long nbad = 0, nacc = 0;
+    for (int it = 0; it < iters; it++) {
+        const unsigned mode = xs32(s) & 7u;
+        // geometry: near-identity rotation rows, small translation, pixel-scale intrinsics; sometimes wild
+        const float wild = (mode == 0) ? 1.0f : 0.0f;
+        for (int i = 0; i < 9; i++) pc->R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + (st_uniform(s) - 0.5f) * (0.1f + wild);
+        for (int i = 0; i < 3; i++) pc->t[i] = (st_uniform(s) - 0.5f) * (0.2f + 10.0f * wild);
+        if (mode == 1) pc->t[2] = 0.0f;
+        pc->nfx = 1.0f + st_uniform(s);
+        pc->nfy = 1.0f + st_uniform(s);
+        pc->ncx = 0.5f + st_uniform(s);
+        pc->ncy = 0.5f + st_uniform(s);
+        const float xp0 = (st_uniform(s) - 0.5f) * 0.6f, xp1 = (st_uniform(s) - 0.5f) * 0.6f;
+        float depthp = (mode == 2) ? st_logmag(s, -60.f, 60.f) : st_logmag(s, -4.f, 4.f);
+        if (mode == 3) depthp = __uint_as_float((__float_as_uint(depthp) | 0x7FFFFFu));  // significand all ones
+        const float dp = rcp_exact(depthp);
+        // what rho_j will be for this geometry (any value works; used to put the taps near the threshold)
+        const float rz = row_dot_xp(pc->R + 6, xp0, xp1);
+        const float depthj = depthp / (rz + depthp * pc->t[2]);
+        for (int k = 0; k < 6; k++) {
+            float sg = (mode == 4) ? st_logmag(s, -30.f, 30.f) : st_logmag(s, -9.f, -2.f);
+            const float crit = 1.9595918f * sg;  // sqrt(3.84) sigma
+            float off;
+            const unsigned m2 = xs32(s) & 3u;
+            if (m2 == 0) off = crit * (1.0f + (st_uniform(s) - 0.5f) * 4.0e-4f);      // inside / around the band
+            else if (m2 == 1) off = crit * (1.0f + (st_uniform(s) - 0.5f) * 2.0e-6f); // rounding distance
+            else off = crit * st_uniform(s) * 3.0f;
+            float rho = depthj + ((xs32(s) & 1u) ? off : -off);
+            const unsigned m3 = xs32(s) & 31u;
+            if (m3 == 0) rho = 0.0f;
+            if (m3 == 1) sg = 0.0f;
+            if (m3 == 2) rho = __builtin_nanf("");
+            if (m3 == 3) sg = __builtin_inff();
+            if (m3 == 4) rho = 5.0e-7f;
+            if (m3 == 5) sg = __uint_as_float((__float_as_uint(sg) | 0x7FFFFFu));
+            nb[k] = make_float2(rho, sg);
+        }
+        __threadfence_block();
+        K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
+        guard_divisor(g0, depthp);
+        const K4Sums in = {(int)(xs32(s) & 3u), (st_uniform(s) - 0.5f) * 10.f, st_uniform(s) * 10.f};
+        bool slow;
+        // W = 3, H = 2: valid projections have 0 <= xj < 2, 0 <= yj < 1
+        const K4Sums a = inter_neighbour_fast(nb, pc, 3, 2.0f, 1.0f, xp0, xp1, depthp, dp, g0, in, &slow);
+        const K4Sums b = inter_neighbour_exact(nb, pc, 3, 2.0f, 1.0f, xp0, xp1, depthp, dp, in);
+        if (!slow) {
+            nacc++;
+            const bool same = a.kf_count == b.kf_count &&
+                              (__float_as_uint(a.sum_Jr) == __float_as_uint(b.sum_Jr) || (a.sum_Jr != a.sum_Jr && b.sum_Jr != b.sum_Jr)) &&
+                              (__float_as_uint(a.sum_JJ) == __float_as_uint(b.sum_JJ) || (a.sum_JJ != a.sum_JJ && b.sum_JJ != b.sum_JJ));
+            if (!same) nbad++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nbad += __shfl_down(nbad, o);
+        nacc += __shfl_down(nacc, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nbad) atomicAdd(bad, nbad);
+        atomicAdd(accepted, nacc);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_selftest_chi(int iters, unsigned long long* __restrict__ bad,
                                                         unsigned long long* __restrict__ inband)
 {

@@ -65,3 +65,15 @@ def test_exact_reciprocal(pkg, gpu_ok):
     assert bad == 0
     assert fast == 2 * 250 * 2 ** 23  # every operand with 2^-125 <= |b| < 2^125 took the reciprocal path
     eng.close()
+
+
+def test_inter_check_fast_body_vs_reference_statement(pkg, gpu_ok):
+    """K4's straight-line per-neighbour body (reciprocal-form quotients, window guards, division-free 3.84 test):
+    wherever it does not raise its slow flag it must equal the plain-division reference statement bit for bit --
+    5*10^8 random cases with magnitudes far outside the windows, taps on the threshold, zero/Inf/NaN operands"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, accepted = eng.selftest(7)
+    assert bad == 0
+    total = 1024 * 256 * 2048
+    assert 0.25 * total < accepted <= total, accepted  # the fast path is the common case, and it is really exercised
+    eng.close()
