@@ -594,6 +594,18 @@ __device__ __forceinline__ bool chi_test_fast(float a, float b, float sa, float 
     return chi_test(a, b, sa, sb);        // band, or NaN from unsafe operands
 }
 
+// the same decision from {rho, 1/sigma^2} pairs; sigma of the second hypothesis is fetched (from LDS) only when
+// the exact test is needed
+__device__ __forceinline__ bool chi_test_lazy(float2 ha, float2 hb, float sa, const float* sb_ptr)
+{
+    float d = ha.x - hb.x;
+    float num = d * d;
+    float approx = num * ha.y + num * hb.y;
+    if (approx < 5.9896f) return true;
+    if (approx > 5.9904f) return false;
+    return chi_test(ha.x, hb.x, sa, *sb_ptr);
+}
+
 __device__ __forceinline__ bool fuse_column(const float2* hyp, int stride, int nh, int lambdaN,
                                             float& rho_o, float& sigma_o)
 {

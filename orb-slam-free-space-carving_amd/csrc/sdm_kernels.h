@@ -329,8 +329,8 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 // footprint at n*64 hypotheses (10 KB at n = 20), which lets 8 waves per SIMD stay resident to
 // hide the gather latency; interleaving j (not blocking it) balances the waves, because the scan
 // length grows with the baseline and neighbours are ordered by covisibility.
-// LDS: float2 hyp[n][64] in neighbour order (rho = NaN marks "no hypothesis", PM.cc:216), their
-// reciprocal variances, and the per-hypothesis compatible-set sizes (bytes): 13 B x n x 64 + 2 KB (18.3 KB at n = 20).
+// LDS: float2 {rho, 1/sigma^2}[n][64] in neighbour order (rho = +Inf marks "no hypothesis", PM.cc:216), sigma[n][64],
+// and the per-hypothesis compatible-set sizes (bytes): 13 B x n x 64 + 2 KB (18.3 KB at n = 20).
 #ifndef SDM_K1_WAVES
 #define SDM_K1_WAVES 4
 #endif
@@ -356,11 +356,13 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                                                        unsigned long long* __restrict__ stats)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    float2* hyp = reinterpret_cast<float2*>(smem_raw);                // [n][64] {rho, sigma}
-    float* rinv = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] 1/sigma^2 (NaN = take the exact path)
+    // [n][64] {rho, 1/sigma^2 (NaN = take the exact path)}: all a pair test reads; sigma itself is needed only by
+    // the exact path, the self pair and the final fusion sum
+    float2* hyp = reinterpret_cast<float2*>(smem_raw);
+    float* sgm = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] sigma
     // compatible-set sizes (<= n <= 64), one byte each: row a lives in byte a&3 of word [a>>2][64].  a is
     // wave-uniform, so the shift is a scalar; a 32-bit LDS atomic add of 1<<8*(a&3) cannot carry over.
-    unsigned* cnt = reinterpret_cast<unsigned*>(rinv + (size_t)n * K1_PX);
+    unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
     const int cnt_words = (n + 3) >> 2;
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
 
@@ -414,8 +416,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                 mymask |= 1ull << j;
             }
         }
-        hyp[j * K1_PX + p] = h;
-        rinv[j * K1_PX + p] = safe_rcp_sq(h.y);
+        hyp[j * K1_PX + p] = make_float2(h.x, safe_rcp_sq(h.y));
+        sgm[j * K1_PX + p] = h.y;
     }
     for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
     pmask[tid] = mymask;
@@ -441,12 +443,12 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
             const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
             if (a >= n || !((vm >> a) & 1ull)) continue;
             const float2 ha = hyp[a * K1_PX + p];
-            const float ra = rinv[a * K1_PX + p];
+            const float sa = sgm[a * K1_PX + p];
             // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
-            unsigned c = (ha.y * ha.y > 0.0f) ? 1u : 0u;
+            unsigned c = (sa * sa > 0.0f) ? 1u : 0u;
             for (int bb = a + 1; bb < n; bb++) {
                 const float2 hb = hyp[bb * K1_PX + p];
-                if (chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p])) {
+                if (chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) {
                     c++;
                     atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
                 }
@@ -472,19 +474,18 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
             }
             if ((int)best >= prm.lambdaN) {  // PM.cc:623
                 const float2 ha = hyp[besta * K1_PX + p];
-                const float ra = rinv[besta * K1_PX + p];
+                const float sa = sgm[besta * K1_PX + p];
                 float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
 #if SDM_ABLATE == 8
-                pjsj = ha.x; rsj = ra;
+                pjsj = ha.x; rsj = ha.y;
                 for (int bb = 0; bb < 0; bb++) {
 #else
                 for (int bb = 0; bb < n; bb++) {
 #endif
                     if (!((vm >> bb) & 1ull)) continue;
                     const float2 hb = hyp[bb * K1_PX + p];
-                    const bool in = (bb == besta) ? (ha.y * ha.y > 0.0f)
-                                                  : chi_test_fast(ha.x, hb.x, ha.y, hb.y, ra, rinv[bb * K1_PX + p]);
-                    if (in) fusion_accum(hb.x, hb.y, pjsj, rsj);
+                    const bool in = (bb == besta) ? (sa * sa > 0.0f) : chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p]);
+                    if (in) fusion_accum(hb.x, sgm[bb * K1_PX + p], pjsj, rsj);
                 }
                 result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
                 n_fused = 1;
