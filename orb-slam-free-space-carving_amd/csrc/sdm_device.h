@@ -276,10 +276,8 @@ __device__ __forceinline__ float match_cost(float pe2, float ge2, const DevParam
     return (float)s;
 }
 
-// (scan tuning macros)
-#ifndef SDM_BRANCHFREE_GATES
-#define SDM_BRANCHFREE_GATES 0
-#endif
+// (build-time knobs: SDM_ABLATE = n compiles one part of the search out -- diagnostic builds for the time
+// attribution in DESIGN.md §5, never shipped; SDM_SCAN_UNROLL = records prefetched per batch)
 #ifndef SDM_ABLATE
 #define SDM_ABLATE 0
 #endif
