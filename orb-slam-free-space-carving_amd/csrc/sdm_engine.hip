@@ -63,13 +63,18 @@ struct sdm_ctx {
     unsigned* d_act = nullptr;     // [max_keyframes][P] active-pixel lists (y<<16|x), raster order
     int* d_act_count = nullptr;    // [max_keyframes]
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
-    std::vector<int> h_act_count;  // host mirror
+    int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
+    bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
     std::vector<char> chk_sparse, xyz_sparse;  // checked / xyz plane of the slot is zero outside its active list
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
                                        // came from elsewhere, e.g. sdm_upload_depth): K4 may use the list
 
     // staging for one keyframe
+    uint8_t* h_im_stage[2] = {nullptr, nullptr};  // pinned ring for host images (sdm_upload_image)
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_next = 0;
     uint8_t* d_im = nullptr;
     float* d_grad = nullptr;
     float* d_theta = nullptr;
@@ -129,7 +134,7 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.default_gates = (c->prm.lambdaL == 80.0f && c->prm.lambdaTheta == 45.0f) ? 1 : 0;
 }
 
-// (re)build the active-pixel list of a slot for the current lambdaG; reads the count back
+// (re)build the active-pixel list of a slot for the current lambdaG; the count comes back asynchronously
 int build_active(sdm_ctx* c, int slot)
 {
     const int n_chunks = (int)((c->P + ACT_BLOCK - 1) / ACT_BLOCK);
@@ -143,9 +148,19 @@ int build_active(sdm_ctx* c, int slot)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&c->h_act_count[slot], c->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost,
                            c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
     c->act_lambdaG[slot] = c->dprm.lambdaG;
     c->epoch++;
+    return SDM_OK;
+}
+
+// the host mirror of the list lengths is valid after this (uploads leave their read-backs in flight)
+int sync_counts(sdm_ctx* c)
+{
+    if (c->counts_pending) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->counts_pending = false;
+    }
     return SDM_OK;
 }
 
@@ -213,6 +228,7 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     for (int r = 0; r < n_ref; r++)  // lists follow lambdaG (sdm_set_params)
         if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG))
             if ((rc = build_active(c, ref_slots[r]))) return rc;
+    if ((rc = sync_counts(c))) return rc;  // callers size their grids from h_act_count
 
     const size_t np = (size_t)n_ref * (size_t)n;
     sdm_ctx::TableKey& k = c->tkey;
@@ -291,11 +307,13 @@ int tables_staged(sdm_ctx* c)
     return SDM_OK;
 }
 
-int push_meta(sdm_ctx* c, int slot)
+// stream-ordered, no copy: the 80-byte record travels as a kernel argument.  keep_istd: leave the device's
+// I_stddev alone (it was derived on the device by the pre-pass; the host holds no mirror of it)
+int push_meta(sdm_ctx* c, int slot, bool keep_istd)
 {
     c->epoch++;
-    HIP_TRY(hipMemcpyAsync(c->d_meta + slot, &c->h_meta[slot], sizeof(KfMeta), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_set_meta, dim3(1), dim3(1), 0, c->stream, c->d_meta + slot, c->h_meta[slot], keep_istd ? 1 : 0);
+    HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
 
@@ -344,10 +362,6 @@ int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
     hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->d_grad, c->d_theta,
                        c->W, c->H, c->rec + (long long)slot * c->P);
     HIP_TRY(hipGetLastError());
-    // mirror the derived I_stddev on the host
-    HIP_TRY(hipMemcpyAsync(&c->h_meta[slot].I_stddev, &c->d_meta[slot].I_stddev, sizeof(float), hipMemcpyDeviceToHost,
-                           c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return build_active(c, slot);
 }
 
@@ -435,7 +449,6 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->h_meta.assign(K, KfMeta{});
     c->has_depth.assign(K, 0);
     c->has_chk.assign(K, 0);
-    c->h_act_count.assign(K, 0);
     c->act_lambdaG.assign(K, std::nanf(""));
     c->recon_lambdaG.assign(K, std::nanf(""));
     c->chk_sparse.assign(K, 1);  // planes start zeroed
@@ -482,6 +495,13 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_tab, c->tab_bytes)) || (rc = host_alloc(&c->h_tab, c->tab_bytes))) return bail(rc);
     if ((rc = dev_alloc(&c->d_refs, K)) || (rc = dev_alloc(&c->d_pairs, np))) return bail(rc);
     if ((rc = host_alloc(&c->h_f2, (size_t)c->P))) return bail(rc);
+    if ((rc = host_alloc(&c->h_act_count, (size_t)K))) return bail(rc);
+    memset(c->h_act_count, 0, sizeof(int) * (size_t)K);
+    for (int b = 0; b < 2; b++) {
+        if ((rc = host_alloc(&c->h_im_stage[b], (size_t)c->P))) return bail(rc);
+        if (hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+    }
     if (hipEventCreateWithFlags(&c->tables_free, hipEventDisableTiming) != hipSuccess)
         return bail(fail(SDM_EHIP, "hipEventCreate failed"));
 
@@ -533,6 +553,11 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_pairs);
     (void)hipHostFree(c->h_tab);
     (void)hipHostFree(c->h_f2);
+    (void)hipHostFree(c->h_act_count);
+    for (int b = 0; b < 2; b++) {
+        (void)hipHostFree(c->h_im_stage[b]);
+        if (c->stage_done[b]) (void)hipEventDestroy(c->stage_done[b]);
+    }
     if (c->tables_free) (void)hipEventDestroy(c->tables_free);
     for (auto& sp : c->spans) {
         (void)hipEventDestroy(sp.a);
@@ -555,6 +580,7 @@ int sdm_set_stream(sdm_ctx* c, void* s)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->counts_pending = false;  // everything queued on the old stream has finished
     if (c->own_stream) {
         (void)hipStreamDestroy(c->stream);
         c->own_stream = false;
@@ -589,8 +615,9 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     fill_meta(m, K, Tcw);
     m.I_stddev = I_stddev;
     m.uploaded = 1;
-    if ((rc = push_meta(c, slot))) return rc;
-    return build_active(c, slot);
+    if ((rc = push_meta(c, slot, false))) return rc;
+    if ((rc = build_active(c, slot))) return rc;
+    return sync_counts(c);  // the caller's (pageable) planes are released on return
 }
 
 int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], const float Tcw[12])
@@ -600,11 +627,22 @@ int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], 
     if (!im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if ((rc = reset_slot(c, slot))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_im, im, (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    // asynchronous: the image is copied into a pinned ring buffer (the caller's buffer is free on return), every
+    // device step is stream-ordered, and nothing here waits for the GPU unless both ring buffers are in flight
+    const int b = c->stage_next;
+    c->stage_next ^= 1;
+    if (c->stage_busy[b]) {
+        HIP_TRY(hipEventSynchronize(c->stage_done[b]));
+        c->stage_busy[b] = false;
+    }
+    memcpy(c->h_im_stage[b], im, (size_t)c->P);
+    HIP_TRY(hipMemcpyAsync(c->d_im, c->h_im_stage[b], (size_t)c->P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->stage_done[b], c->stream));
+    c->stage_busy[b] = true;
     KfMeta& m = c->h_meta[slot];
     fill_meta(m, K, Tcw);
     m.uploaded = 1;
-    if ((rc = push_meta(c, slot))) return rc;
+    if ((rc = push_meta(c, slot, true))) return rc;
     return prepass_and_pack(c, slot, c->d_im);
 }
 
@@ -618,8 +656,9 @@ int sdm_upload_image_device(sdm_ctx* c, int slot, const void* d_im, const float 
     KfMeta& m = c->h_meta[slot];
     fill_meta(m, K, Tcw);
     m.uploaded = 1;
-    if ((rc = push_meta(c, slot))) return rc;
-    return prepass_and_pack(c, slot, (const uint8_t*)d_im);
+    if ((rc = push_meta(c, slot, true))) return rc;
+    if ((rc = prepass_and_pack(c, slot, (const uint8_t*)d_im))) return rc;
+    return sync_counts(c);  // the caller's device image has been consumed on return
 }
 
 int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
@@ -628,7 +667,7 @@ int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
     if (rc) return rc;
     if (!Tcw) return fail(SDM_EINVAL, "null pose");
     memcpy(c->h_meta[slot].Tcw, Tcw, sizeof(float) * 12);
-    return push_meta(c, slot);
+    return push_meta(c, slot, true);
 }
 
 int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* theta, float* I_stddev)
@@ -642,8 +681,9 @@ int sdm_download_inputs(sdm_ctx* c, int slot, uint8_t* im, float* grad, float* t
     if (im) HIP_TRY(hipMemcpyAsync(im, c->d_im, (size_t)c->P, hipMemcpyDeviceToHost, c->stream));
     if (grad) HIP_TRY(hipMemcpyAsync(grad, c->d_grad, sizeof(float) * c->P, hipMemcpyDeviceToHost, c->stream));
     if (theta) HIP_TRY(hipMemcpyAsync(theta, c->d_theta, sizeof(float) * c->P, hipMemcpyDeviceToHost, c->stream));
+    if (I_stddev)
+        HIP_TRY(hipMemcpyAsync(I_stddev, &c->d_meta[slot].I_stddev, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (I_stddev) *I_stddev = c->h_meta[slot].I_stddev;
     return SDM_OK;
 }
 

@@ -506,6 +506,13 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     }
 }
 
+// per-slot metadata written in stream order (80 bytes as a kernel argument: no copy, no host synchronisation)
+__global__ void k_set_meta(KfMeta* __restrict__ dst, KfMeta m, int keep_istd)
+{
+    if (keep_istd) m.I_stddev = dst->I_stddev;
+    *dst = m;
+}
+
 // ---- shared halo loader for the 3x3 stencil kernels -----------------------------------------------------
 constexpr int HALO_W = TILE_W + 2;
 constexpr int HALO_H = TILE_H + 2;
