@@ -177,7 +177,7 @@ int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long laun
  * which 2: fast matching cost (PM.cc:436) vs the reference expression incl. rounding midpoints;
  * which 3: closed-form angle gates (PM.cc:414-431) vs the reference statement;
  * which 4: GetFusion's shared-reciprocal double quotients (PM.cc:956-957) vs plain divisions;
- * which 5: float quotients sharing a divisor (K4, PM.cc:678-680,782-783) vs IEEE divisions;
+ * which 5: reciprocal-form float quotients (K4, PM.cc:678-680,782-783) vs IEEE divisions inside the operand window;
  * which 6: reciprocal + one FMA step (K4/K5, PM.cc:769,777,793,349) vs IEEE 1/b over all 2^32 float inputs;
  * which 7: K4's straight-line per-neighbour body vs the reference statement (PM.cc:677-755,777-783) on 5*10^8
  *          random geometries / 2x2 tap patches; out[1] = cases whose fast result was accepted. */

@@ -541,30 +541,34 @@ __device__ __forceinline__ float rcp_exact(float b)
     return __builtin_fmaf(e, r, r);
 }
 
-// ---- float quotients that share a divisor -------------------------------------------------------------------
-// a/b from r = 1.0f/b (a true, correctly rounded division done once) with two FMA residual
-// corrections (Markstein): bit-identical to the IEEE quotient provided b's significand is not all
-// ones and nothing leaves the normal range -- quot_ok_* check exactly that; otherwise the caller
-// divides.  sdm_selftest(5) compares both forms over 2^33 operand pairs.
-__device__ __forceinline__ bool quot_ok_divisor(float b)
+// ---- float quotients in reciprocal form (K4) ------------------------------------------------------------------
+// a/b as q = a*r with two FMA residual corrections (Markstein), r = 1/b correctly rounded (rcp_fast: v_rcp_f32 +
+// one FMA step, see rcp_exact).  Bit-identical to the IEEE quotient whenever |a| and |b| lie in [2^-40, 2^41) and
+// b's significand is not all ones -- quot_window_ok states exactly that; K4 folds the same test over all operands
+// of a neighbour into running integer min/max (NaN and Inf land above the window) instead of testing per quotient.
+// sdm_selftest(5) compares quot_fast with the division over 2^33 operand pairs in and around the window.
+constexpr unsigned QUOT_MAG_LO = 87u << 23;          // 2^-40
+constexpr unsigned QUOT_MAG_HI = (168u << 23) - 1u;  // just below 2^41
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ float rcp_fast(float b)
 {
-    unsigned u = __float_as_uint(b);
-    unsigned e = (u >> 23) & 0xffu;
-    return (e >= 64u) & (e <= 190u) & ((u & 0x7FFFFFu) != 0x7FFFFFu);  // |b| in [2^-63, 2^63]
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
 }
-__device__ __forceinline__ bool quot_ok_numerator(float a)
+__device__ __forceinline__ float quot_fast(float a, float b, float r)
 {
-    unsigned e = (__float_as_uint(a) >> 23) & 0xffu;
-    return ((e >= 87u) & (e <= 167u)) | (a == 0.0f);  // 0 or |a| in [2^-40, 2^40]
-}
-__device__ __forceinline__ float quot_with_rcp(float a, float b, float r, bool b_ok)
-{
-    if (__builtin_expect(!(b_ok && quot_ok_numerator(a)), 0)) return a / b;
     float q0 = a * r;
     float e0 = __builtin_fmaf(-q0, b, a);
     float q1 = __builtin_fmaf(e0, r, q0);
     float e1 = __builtin_fmaf(-q1, b, a);
     return __builtin_fmaf(e1, r, q1);
+}
+__device__ __forceinline__ bool quot_window_ok(float a, float b)
+{
+    const unsigned ua = absbits(a), ub = absbits(b);
+    return (ua >= QUOT_MAG_LO) & (ua <= QUOT_MAG_HI) & (ub >= QUOT_MAG_LO) & (ub <= QUOT_MAG_HI) &
+           ((__float_as_uint(b) & 0x7FFFFFu) != 0x7FFFFFu);
 }
 
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.

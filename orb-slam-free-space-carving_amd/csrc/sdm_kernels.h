@@ -770,11 +770,9 @@ struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizon
 struct K4Guard {
     unsigned hi, lo, ones;  // max / min of |operand| bit patterns; min over divisors of ((bits | ~mant) + 1): 0 = all ones
 };
-constexpr unsigned K4_MAG_LO = 87u << 23;          // 2^-40
-constexpr unsigned K4_MAG_HI = (168u << 23) - 1u;  // just below 2^41
+constexpr unsigned K4_MAG_LO = QUOT_MAG_LO, K4_MAG_HI = QUOT_MAG_HI;  // the quotient window (sdm_device.h)
 constexpr unsigned K4_TAP_LO = 114u << 23;          // 2^-13
 constexpr unsigned K4_TAP_HI = (140u << 23) - 1u;  // just below 2^13
-__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
 __device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
 __device__ __forceinline__ void guard2(K4Guard& g, float a, float b)
@@ -787,21 +785,6 @@ __device__ __forceinline__ void guard_divisor(K4Guard& g, float b)
 {
     g.ones = min(g.ones, (__float_as_uint(b) | 0xFF800000u) + 1u);
 }
-__device__ __forceinline__ float rcp_fast(float b)
-{
-    const float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ float quot_fast(float a, float b, float r)
-{
-    float q0 = a * r;
-    float e0 = __builtin_fmaf(-q0, b, a);
-    float q1 = __builtin_fmaf(e0, r, q0);
-    float e1 = __builtin_fmaf(-q1, b, a);
-    return __builtin_fmaf(e1, r, q1);
-}
-
 // the reference statement for one neighbour (PM.cc:677-755, 777-783), given the rows already fetched when the
 // projection agreed (ra/rb are re-read here because an inexact fast projection may have addressed another pixel)
 struct K4Sums {
@@ -1420,7 +1403,8 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_fusion_terms(int iters, unsi
     }
 }
 
-// which = 5: float quotient from a shared reciprocal (quot_with_rcp) vs the IEEE division.
+// which = 5: reciprocal-form float quotient (quot_fast, K4) vs the IEEE division, wherever quot_window_ok holds;
+// operands are spread over and beyond the window, all significands, both signs.  tested = pairs inside the window.
 __global__ __launch_bounds__(BLOCK) void k_selftest_quot(int iters, unsigned long long* __restrict__ bad,
                                                          unsigned long long* __restrict__ tested)
 {
@@ -1428,15 +1412,14 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_quot(int iters, unsigned lon
     unsigned long long cnt = 0, n = 0;
     for (int i = 0; i < iters; i++) {
         unsigned ba = xs32(s), bb = xs32(s);
-        // exponents spread over and beyond the guarded ranges; all mantissas; both signs
-        float a = __uint_as_float((ba & 0x807FFFFFu) | ((70u + (ba >> 23) % 114u) << 23));
-        float b = __uint_as_float((bb & 0x807FFFFFu) | ((50u + (bb >> 23) % 154u) << 23));
+        float a = __uint_as_float((ba & 0x807FFFFFu) | ((80u + (ba >> 23) % 96u) << 23));   // 2^-47 .. 2^48
+        float b = __uint_as_float((bb & 0x807FFFFFu) | ((80u + (bb >> 23) % 96u) << 23));
         unsigned pick = xs32(s);
         if ((pick & 127u) == 0) a = 0.0f;
         if ((pick & 127u) == 1) b = __uint_as_float(__float_as_uint(b) | 0x7FFFFFu);  // all-ones significand
         if ((pick & 127u) == 2) a = __uint_as_float(__float_as_uint(b) + ((pick >> 8) & 3u));  // a ~ b
-        float r = 1.0f / b;
-        float q = quot_with_rcp(a, b, r, quot_ok_divisor(b));
+        if (!quot_window_ok(a, b)) continue;
+        float q = quot_fast(a, b, rcp_fast(b));
         float e = a / b;
         if (!(q == e || (q != q && e != e))) cnt++;
         n++;

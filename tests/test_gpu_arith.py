@@ -50,11 +50,12 @@ def test_fusion_terms_shared_reciprocal(pkg, gpu_ok):
 
 
 def test_shared_divisor_quotient(pkg, gpu_ok):
-    """a/b from one reciprocal + two FMA corrections == IEEE division (guards route the rest)"""
+    """a/b as a*r with two FMA corrections, r = v_rcp_f32 + one FMA step (K4's quot_fast / rcp_fast) == IEEE division
+    for every operand pair inside the quotient window [2^-40, 2^41), divisor significand not all ones"""
     eng = pkg.Engine(64, 48, 2)
     bad, tested = eng.selftest(5)
     assert bad == 0
-    assert tested >= 2 ** 33
+    assert tested >= 5 * 10 ** 9  # pairs that were inside the window (of 8.6e9 drawn in and around it)
     eng.close()
 
 
