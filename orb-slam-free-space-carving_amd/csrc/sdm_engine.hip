@@ -353,11 +353,11 @@ int pack_staged(sdm_ctx* c, int slot)
 // gradient pre-pass from c->d_im (or an external device image) into the staging planes + records
 int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
 {
-    HIP_TRY(hipMemsetAsync(c->d_sums, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_gradient, dim3(c->geom.ntiles), dim3(BLOCK), 0, c->stream, d_image, c->W, c->H, c->d_grad,
                        c->d_theta, c->d_sums);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_istd_finish, dim3(1), dim3(1), 0, c->stream, c->d_sums, c->W, c->H, c->d_meta + slot);
+    hipLaunchKernelGGL(k_istd_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->d_sums, c->geom.ntiles, c->W, c->H,
+                       c->d_meta + slot);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->d_grad, c->d_theta,
                        c->W, c->H, c->rec + (long long)slot * c->P);
@@ -487,7 +487,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_sums, 2))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_sums, 2 * (size_t)c->geom.ntiles))) return bail(rc);  // per-tile {sum, sum of squares}
     if ((rc = dev_alloc(&c->d_small, 16))) return bail(rc);
     if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
     const size_t np = (size_t)K * cfg->max_neighbours;

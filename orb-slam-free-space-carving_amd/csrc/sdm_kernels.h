@@ -122,23 +122,56 @@ __global__ __launch_bounds__(BLOCK) void k_gradient(const uint8_t* __restrict__ 
             sq += (unsigned long long)(a11 * a11);
         }
     }
+    // per-tile partial sums (integers: any order gives the same total); same-address atomics from every wave
+    // serialised the whole kernel (34 us at 640x480), so each workgroup writes its own pair instead
+    __shared__ unsigned long long wsum[2][BLOCK / 64];
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o);
         sq += __shfl_down(sq, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&sums[0], s);
-        atomicAdd(&sums[1], sq);
+        wsum[0][threadIdx.x >> 6] = s;
+        wsum[1][threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < BLOCK / 64; w++) tot += wsum[threadIdx.x][w];
+        sums[2 * blockIdx.x + threadIdx.x] = tot;
     }
 }
 
-__global__ void k_istd_finish(const unsigned long long* __restrict__ sums, int W, int H, KfMeta* meta)
+// I_stddev = population sigma of im (PM.cc:457) from the per-tile sums; one workgroup
+__global__ __launch_bounds__(BLOCK) void k_istd_finish(const unsigned long long* __restrict__ sums, int ntiles, int W,
+                                                       int H, KfMeta* meta)
 {
-    double n = (double)W * (double)H;
-    double mean = (double)sums[0] / n;
-    double var = (double)sums[1] / n - mean * mean;
-    if (var < 0) var = 0;
-    meta->I_stddev = (float)sqrt(var);
+    __shared__ unsigned long long wsum[2][BLOCK / 64];
+    unsigned long long s = 0, sq = 0;
+    for (int i = threadIdx.x; i < ntiles; i += BLOCK) {
+        s += sums[2 * i];
+        sq += sums[2 * i + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        sq += __shfl_down(sq, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wsum[0][threadIdx.x >> 6] = s;
+        wsum[1][threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ts = 0, tq = 0;
+        for (int w = 0; w < BLOCK / 64; w++) {
+            ts += wsum[0][w];
+            tq += wsum[1][w];
+        }
+        double n = (double)W * (double)H;
+        double mean = (double)ts / n;
+        double var = (double)tq / n - mean * mean;
+        if (var < 0) var = 0;
+        meta->I_stddev = (float)sqrt(var);
+    }
 }
 
 // pack im/grad/theta planes into the 16-byte search records (layout: sdm_device.h)
