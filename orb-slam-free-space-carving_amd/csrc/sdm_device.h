@@ -363,7 +363,10 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     int lo = (int)ceilf(umin);
     int hi = (int)floorf(umax);
     if (hi > W - 1) hi = W - 1;
-    const float hlim = (float)(H - 1), hlim2 = (float)(H - 2);
+    const float hlim2 = (float)(H - 2);
+    // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged (and its
+    // integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3 in one comparison
+    const float hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
     const char* __restrict__ nbase = reinterpret_cast<const char*>(nrec);
     // PM.cc:405 scan.  Candidates are visited in increasing uj exactly as the reference does (the
     // strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four
@@ -386,15 +389,17 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
     for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
+        unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
         v4f rs[SCAN_UNROLL];
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
             int uj = u0 + k;
             float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
-            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim2);
+            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
             unsigned uc16 = min(((unsigned)u0 << 4) + 16u * k, hi16);  // min(uj, hi) * 16
             unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
             yfs[k] = yf;
+            rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
 #if SDM_ABLATE == 5
             rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
 #else
@@ -412,7 +417,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
             if (STATS && uj <= hi) st->candidates++;
             const float yf = yfs[k];
             const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
-            if (!((uj <= hi) & (yf >= 1.0f) & (yf < hlim))) continue;  // PM.cc:408 + N3
+            if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
             if (r.x < prm.lambdaG) continue;                            // PM.cc:411
 #if SDM_ABLATE == 4
             if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
