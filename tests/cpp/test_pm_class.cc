@@ -59,6 +59,8 @@ int main(int argc, char** argv)
     sdm::Options opt;
     opt.covisN = covisN;
     opt.max_keyframes = n_kf;
+    if (const char* cap = getenv("SDM_TEST_MAX_KF"))  // fewer device slots than keyframes: exercises the LRU eviction,
+        if (atoi(cap) > 0) opt.max_keyframes = atoi(cap);  // re-upload and PushDepth paths
     ProbabilityMapping pm(&map, opt);
 
     for (int k = 0; k < n_kf; k++) pm.SemiDenseRecon(&kfs[k]);

@@ -25,9 +25,11 @@ def build_driver(pkg):
     return exe
 
 
-def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path):
+@pytest.mark.parametrize("n_kf,n,max_kf", [(10, 7, 0), (14, 4, 6)])
+def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path, n_kf, n, max_kf):
+    """max_kf > 0: fewer device slots than keyframes, so keyframes are evicted (LRU) and re-uploaded with their
+    depth maps when a later keyframe's check needs them -- the results must not change"""
     exe = build_driver(pkg)
-    n_kf, n = 10, 7
     seq = Sequence(pkg, oracle, 96, 72, n_kf, 0x5EED0E01)
     W, H = seq.W, seq.H
     rng = np.random.default_rng(0)
@@ -47,7 +49,7 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path):
     out = tmp_path / "out.bin"
     obj = tmp_path / "cloud.obj"
     tr = tmp_path / "transcript.txt"
-    subprocess.check_call([exe, str(blob), str(out), str(obj), str(tr)])
+    subprocess.check_call([exe, str(blob), str(out), str(obj), str(tr)], env=dict(os.environ, SDM_TEST_MAX_KF=str(max_kf)))
 
     # ---- the same schedule on the oracle ----------------------------------------------------------
     nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
@@ -135,4 +137,5 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path):
     got = open(tr).read().split("\n")
     assert got[-1] == ""
     assert got[:-1] == want
-    assert sum(1 for l in want if l.startswith("new point")) > 50
+    if n >= 7:  # with few neighbours hardly any point passes the sigma filter; the text comparison above still holds
+        assert sum(1 for l in want if l.startswith("new point")) > 50
