@@ -554,3 +554,32 @@ def test_inter_check_threshold_sweep(pkg, oracle, gpu_ok):
     kept = int((ref > 1e-6).sum())
     assert 0.2 * W * H < kept < 0.8 * W * H, kept  # the sweep really straddles the threshold
     eng.close()
+
+
+def test_flat_images_have_no_work(pkg, oracle, gpu_ok):
+    """constant images: no pixel passes the gradient gate (PM.cc:201), every stage is a no-op, nothing is launched
+    with an empty grid; one textured keyframe among flat neighbours finds no hypotheses either"""
+    W, H, n_kf, n = 96, 64, 5, 3
+    rng = np.random.default_rng(5)
+    K = np.float32([120.0, 120.0, 47.5, 31.5])
+    ims = [np.full((H, W), 128, np.uint8) for _ in range(n_kf)]
+    ims[2] = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    eng = pkg.Engine(W, H, n_kf, max_neighbours=n, with_pointset=True)
+    okf = []
+    for k in range(n_kf):
+        Tcw = np.concatenate([np.eye(3), np.float32([[0.02 * k], [0.0], [0.0]])], axis=1).astype(np.float32)
+        eng.upload_image(k, ims[k], K, Tcw)
+        g, th, s = oracle.gradient_prepass(ims[k])
+        okf.append(oracle.keyframe(ims[k], g, th, s, K, Tcw))
+    refs = list(range(n_kf))
+    nbrs = [[j for j in range(n_kf) if j != k][:n] for k in refs]
+    eng.recon(refs, nbrs, 0.5, 2.0)
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    for k in refs:
+        r, s, _ = oracle.semi_dense_recon(okf[k], [okf[j] for j in nbrs[k]], None, 0.5, 2.0)
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, r, "flat rho kf %d" % k)
+        assert_bit_equal(gs, s, "flat sigma kf %d" % k)
+        assert not gr.any() and not eng.download_checked(k).any() and not eng.download_pointset(k).any()
+    eng.close()
