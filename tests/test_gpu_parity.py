@@ -583,3 +583,37 @@ def test_flat_images_have_no_work(pkg, oracle, gpu_ok):
         assert_bit_equal(gs, s, "flat sigma kf %d" % k)
         assert not gr.any() and not eng.download_checked(k).any() and not eng.download_pointset(k).any()
     eng.close()
+
+
+@pytest.mark.parametrize("W,H", [(8, 8), (9, 17), (131, 67), (64, 8)])
+def test_tiny_and_odd_sizes(pkg, oracle, gpu_ok, W, H):
+    """the smallest image the engine accepts and odd sizes: whole path against the oracle (noise images so that
+    the gradient gate passes; any hypotheses that survive must agree)"""
+    n_kf, n = 4, 3
+    rng = np.random.default_rng(W * 1000 + H)
+    K = np.float32([1.2 * W, 1.2 * W, (W - 1) / 2.0, (H - 1) / 2.0])
+    base = rng.integers(0, 256, (H, W + 8)).astype(np.uint8)
+    eng = pkg.Engine(W, H, n_kf, max_neighbours=n, with_pointset=True)
+    okf = []
+    for k in range(n_kf):
+        im = np.ascontiguousarray(base[:, k:k + W])  # one-pixel shifts: true matches exist
+        Tcw = np.concatenate([np.eye(3), np.float32([[-k / (1.2 * W)], [0.0], [0.0]])], axis=1).astype(np.float32)
+        eng.upload_image(k, im, K, Tcw)
+        g, th, s = oracle.gradient_prepass(im)
+        okf.append(oracle.keyframe(im, g, th, s, K, Tcw))
+    refs = list(range(n_kf))
+    nbrs = [[j for j in range(n_kf) if j != k][:n] for k in refs]
+    eng.recon(refs, nbrs, 0.25, 4.0)
+    rho, sig = {}, {}
+    for k in refs:
+        rho[k], sig[k], _ = oracle.semi_dense_recon(okf[k], [okf[j] for j in nbrs[k]], None, 0.25, 4.0)
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, rho[k], "%dx%d rho kf %d" % (W, H, k))
+        assert_bit_equal(gs, sig[k], "%dx%d sigma kf %d" % (W, H, k))
+    eng.inter_check(refs, nbrs)
+    eng.pointset(refs, source=1)
+    for k in refs:
+        c = oracle.inter_check(okf[k], rho[k], [okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]], [sig[j] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), c, "%dx%d checked kf %d" % (W, H, k))
+        assert_bit_equal(eng.download_pointset(k), oracle.pointset(okf[k], c), "%dx%d xyz kf %d" % (W, H, k))
+    eng.close()
