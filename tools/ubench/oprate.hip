@@ -4,6 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/oprate.hip -o oprate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #define REP16(X) X X X X X X X X X X X X X X X X
 
@@ -90,6 +91,19 @@ KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %1, %1, %2, %3\n v_or3_b32 %
 KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1")
 KERNEL(k_fma_neg, "v_fma_f32 %0, -%0, %1, %2\n v_fma_f32 %1, -%1, %2, %3\n v_fma_f32 %2, -%2, %3, %0\n v_fma_f32 %3, -%3, %0, %1")
 
+KERNEL(k_mix_fs, "v_add_f32 %0, 1.0, %0\n v_cvt_f32_i32 %1, %1\n v_add_f32 %2, 1.0, %2\n v_cvt_f32_i32 %3, %3")
+KERNEL(k_mix_ft, "v_add_f32 %0, 1.0, %0\n v_rcp_f32 %1, %1\n v_add_f32 %2, 1.0, %2\n v_add_f32 %3, 1.0, %3")
+KERNEL(k_mix_st, "v_cvt_f32_i32 %0, %0\n v_rcp_f32 %1, %1\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3")
+
+// pairing rules: two dependent chains A (%0) and B (%1), ordered AABB vs ABAB; and fast ops whose neighbours are slow ops of the SAME chain
+KERNEL(k_pair_aabb, "v_add_f32 %0, 1.0, %0\n v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %1, 1.0, %1")
+KERNEL(k_pair_abab, "v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1")
+KERNEL(k_pair_dep_fs, "v_add_f32 %0, 1.0, %0\n v_cvt_f32_i32 %0, %0\n v_add_f32 %1, 1.0, %1\n v_cvt_f32_i32 %1, %1")
+KERNEL(k_pair_cmp_add, "v_cmp_lt_f32 vcc, %0, %1\n v_add_f32 %2, 1.0, %2\n v_cmp_lt_f32 vcc, %1, %0\n v_add_f32 %3, 1.0, %3")
+KERNELS(k_pair_cnd_add, "v_cndmask_b32_e64 %0, %0, %1, s[40:41]\n v_add_f32 %2, 1.0, %2\n v_cndmask_b32_e64 %1, %1, %0, s[40:41]\n v_add_f32 %3, 1.0, %3")
+KERNEL64(k_pair_f64_add, "v_mul_f64 v[60:61], v[60:61], v[62:63]\n v_add_f32 %2, 1.0, %2\n v_add_f64 v[62:63], v[62:63], v[60:61]\n v_add_f32 %3, 1.0, %3")
+KERNELS(k_pair_sgpr_add, "v_add_f32 %0, s42, %0\n v_add_f32 %2, 1.0, %2\n v_add_f32 %1, s42, %1\n v_add_f32 %3, 1.0, %3")
+
 typedef void (*kern_t)(float*, int, float);
 double run(kern_t k, int blocks, int iters, float* d_out)
 {
@@ -105,11 +119,12 @@ double run(kern_t k, int blocks, int iters, float* d_out)
     (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
 }
-int main()
+int main(int argc, char** argv)
 {
     float* d_out;
     (void)hipMalloc(&d_out, sizeof(float) * 256 * 4096);
-    const int iters = 4000, blocks = 256 * 8;  // 32 waves per CU = 8 per SIMD
+    const int wps = argc > 1 ? atoi(argv[1]) : 8;  // waves per SIMD (1, 2, 4 or 8)
+    const int iters = 4000, blocks = 256 * wps;    // 4 waves per workgroup, 256 CUs
     struct { const char* name; kern_t k; } tab[] = {
         {"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_and_b32", k_and_b32}, {"v_add_u32", k_add_u32},
         {"v_max_u32", k_max_u32}, {"v_max3_u32", k_max3_u32}, {"v_med3_f32", k_med3_f32}, {"v_max_f32", k_max_f32},
@@ -123,9 +138,14 @@ int main()
         {"v_sub_f32", k_sub_f32}, {"v_or_b32", k_or_b32}, {"v_lshl_or_b32", k_lshl_or}, {"v_add_f32 |abs| (VOP3)", k_add_abs},
         {"v_add_f32 literal", k_add_lit}, {"v_and_b32 literal", k_and_lit}, {"v_add_lshl_u32", k_add_lshl}, {"v_min_i32", k_min_i32},
         {"v_ashrrev_i32", k_ashr}, {"v_xor_b32", k_xor}, {"v_cvt_f32_ubyte0/1", k_ubyte}, {"v_sub_u32", k_sub_u32},
-        {"v_or3_b32", k_or3}, {"v_fmac_f32", k_fmac}, {"v_fma_f32 neg", k_fma_neg}};
+        {"v_or3_b32", k_or3}, {"v_fmac_f32", k_fmac}, {"v_fma_f32 neg", k_fma_neg},
+        {"mix: 2 fast + 2 slow (add, cvt)", k_mix_fs}, {"mix: 3 fast + 1 rcp", k_mix_ft}, {"mix: 3 slow + 1 rcp", k_mix_st},
+        {"2 dependent chains, order AABB", k_pair_aabb}, {"2 dependent chains, order ABAB", k_pair_abab},
+        {"add->cvt dependent, 2 chains", k_pair_dep_fs}, {"cmp + independent add", k_pair_cmp_add},
+        {"cndmask(sgpr mask) + independent add", k_pair_cnd_add}, {"f64 mul/add + independent add", k_pair_f64_add},
+        {"add(sgpr src) + independent add", k_pair_sgpr_add}};
     // instructions per SIMD: 8 waves * iters * 16 * 4
-    const double n_per_simd = 8.0 * iters * 64.0;
+    const double n_per_simd = (double)wps * iters * 64.0;
     double base = 0;
     for (auto& t : tab) {
         double ms = run(t.k, blocks, iters, d_out);
