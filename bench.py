@@ -176,7 +176,7 @@ def main():
         "config": {
             "workload": "%dx%d, %d keyframes/GPU x %d covisible neighbours, synthetic gradient images "
                         "(BASELINE.json configs[1])" % (W, H, args.kfs, N),
-            "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5)" %
+            "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" %
                       ("no exchange (1 GPU)" if world == 1 else args.exchange + " exchange of {rho,sigma} maps (RCCL)"),
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
             "parallelism": "keyframe-block x%d" % world, "arch": arch,

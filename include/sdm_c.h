@@ -116,6 +116,11 @@ int sdm_inter_check(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const 
 /* ---- UpdateSemiDensePointSet, PM.h:88 / PM.cc:337-367 ----------------------------------------- */
 /* source: 0 = depth map, 1 = checked plane.  Needs with_pointset. */
 int sdm_pointset(sdm_ctx *ctx, int n_ref, const int *ref_slots, int source);
+/* sdm_inter_check followed by sdm_pointset(source = 1) -- the pair the reference runs per ready keyframe
+ * (PM.cc:300-306) -- with the back-projection done in the checking kernel when the maps came out of
+ * SemiDenseRecon; identical results to the two calls. */
+int sdm_inter_check_pointset(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *nbr_slots,
+                             int commit);
 
 /* ---- map transfer ------------------------------------------------------------------------------ */
 int sdm_upload_depth(sdm_ctx *ctx, int slot, const float *rho, const float *sigma);

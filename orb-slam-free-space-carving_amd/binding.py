@@ -64,6 +64,7 @@ SYMBOLS = [
     ("sdm_recon", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, _f32p, _f32p, _f32p]),
     ("sdm_inter_check", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, C.c_int]),
     ("sdm_pointset", C.c_int, [_ctx, C.c_int, _ip, C.c_int]),
+    ("sdm_inter_check_pointset", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, C.c_int]),
     ("sdm_upload_depth", C.c_int, [_ctx, C.c_int, _f32p, _f32p]),
     ("sdm_download_depth", C.c_int, [_ctx, C.c_int, _f32p, _f32p]),
     ("sdm_download_checked", C.c_int, [_ctx, C.c_int, _f32p]),
@@ -265,6 +266,13 @@ class Engine:
         nbrs = np.ascontiguousarray(nbrs, dtype=np.int32).reshape(len(refs), -1)
         self._check(self.lib.sdm_inter_check(self.ctx, len(refs), refs.ctypes.data_as(_ip), nbrs.shape[1],
                                              nbrs.ctypes.data_as(_ip), 1 if commit else 0))
+
+    def inter_check_pointset(self, refs, nbrs, commit=False):
+        """inter_check + pointset(source=1) in one call (PM.cc:300-306); one kernel for maps from SemiDenseRecon"""
+        refs = np.ascontiguousarray(refs, dtype=np.int32).reshape(-1)
+        nbrs = np.ascontiguousarray(nbrs, dtype=np.int32).reshape(len(refs), -1)
+        self._check(self.lib.sdm_inter_check_pointset(self.ctx, len(refs), refs.ctypes.data_as(_ip), nbrs.shape[1],
+                                                      nbrs.ctypes.data_as(_ip), 1 if commit else 0))
 
     def pointset(self, refs, source=1):
         r, rp = _i32(np.asarray(refs).reshape(-1))

@@ -865,12 +865,14 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
 }
 
 // ---- K4 / K5 ------------------------------------------------------------------------------------------------------
-int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, int commit)
+static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, int commit,
+                            bool want_xyz, bool* xyz_done)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    *xyz_done = false;
     {
         StageTimer tm(c, SDM_STAGE_INTER);
         bool from_recon = true;  // every reference map produced by SemiDenseRecon under the current lambdaG?
@@ -888,12 +890,22 @@ int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
                 HIP_TRY(hipGetLastError());
             }
             for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 1;
+            // the point set can ride along when its plane is zero outside the lists as well (K5's list form)
+            bool fuse = want_xyz && c->xyz != nullptr;
+            for (int r = 0; r < n_ref && fuse; r++) fuse = c->xyz_sparse[ref_slots[r]] != 0;
             if (max_chunks > 0) {
-                hipLaunchKernelGGL(k_inter_check_list, dim3(8 * ((max_chunks + 7) / 8) * n_ref), dim3(BLOCK), 0,
-                                   c->stream, c->pool, c->P, c->d_refs, c->d_pairs, n_ref, n, c->W, c->H, max_chunks,
-                                   c->dprm.lambdaN, c->d_act, c->chk);
+                const dim3 grid(8 * ((max_chunks + 7) / 8) * n_ref);
+                if (fuse)
+                    hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P, c->d_refs,
+                                       c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm.lambdaN, c->d_act, c->chk,
+                                       c->d_meta, c->xyz);
+                else
+                    hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P, c->d_refs,
+                                       c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm.lambdaN, c->d_act, c->chk,
+                                       c->d_meta, c->xyz);
                 HIP_TRY(hipGetLastError());
             }
+            *xyz_done = fuse;
         } else {
             for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 0;  // the generic kernel copies arbitrary maps
             hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
@@ -908,6 +920,22 @@ int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const in
     }
     for (int r = 0; r < n_ref; r++) c->has_chk[ref_slots[r]] = 1;  // kf->interKF_depth_flag_, PM.cc:306
     return tables_staged(c);
+}
+
+int sdm_inter_check(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, int commit)
+{
+    bool xyz_done;
+    return inter_check_core(c, n_ref, ref_slots, n, nbr_slots, commit, false, &xyz_done);
+}
+
+int sdm_inter_check_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr_slots, int commit)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (!c->xyz) return fail(SDM_ESTATE, "context created without with_pointset");
+    bool xyz_done = false;
+    int rc = inter_check_core(c, n_ref, ref_slots, n, nbr_slots, commit, true, &xyz_done);
+    if (rc || xyz_done) return rc;
+    return sdm_pointset(c, n_ref, ref_slots, 1);  // maps that are not pipeline maps: the two passes
 }
 
 int sdm_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int source)

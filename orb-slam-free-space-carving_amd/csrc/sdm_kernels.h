@@ -1014,15 +1014,39 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check(const float2* __restrict_
     }
 }
 
+// one pixel of UpdateSemiDensePointSet (PM.cc:345-363): Pw = Twc * [Z(x-cx)/fx, Z(y-cy)/fy, Z, 1], Z = 1/rho
+__device__ __forceinline__ void pointset_pixel(const KfMeta& m, int x, int y, float inv_d, float* __restrict__ o)
+{
+    if (lt_1em6(inv_d)) {  // PM.cc:345
+        o[0] = 0.f;
+        o[1] = 0.f;
+        o[2] = 0.f;
+        return;
+    }
+    float Rwc[9], Ow[3], tcw[3] = {m.Tcw[3], m.Tcw[7], m.Tcw[11]};  // Twc, src/KeyFrame.cc:70-84
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) Rwc[i * 3 + k] = m.Tcw[k * 4 + i];
+    mat3_vec(Rwc, tcw, Ow);
+    float Z = rcp_exact(inv_d);
+    float X = Z * ((float)x - m.cx) / m.fx;
+    float Y = Z * ((float)y - m.cy) / m.fy;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = ((Rwc[i * 3 + 0] * X + Rwc[i * 3 + 1] * Y) + Rwc[i * 3 + 2] * Z) + (-Ow[i]) * 1.0f;
+}
+
 // Pipeline form: the depth map was produced by SemiDenseRecon, so every supported pixel is in the
 // keyframe's active-pixel list (K1 writes only listed pixels, K2 only removes support, K3 grows
 // only pixels with GradImg >= lambdaG).  One thread per list entry, no LDS; every listed pixel of the
 // checked plane is written, the rest of it must already equal rho (= 0) -- else k_rho_copy runs first.
+// XYZ: also back-project the checked value (the reference calls UpdateSemiDensePointSet right after
+// InterKeyFrameDepthChecking, PM.cc:300-306): saves the second pass over the list and the checked plane.
+template <bool XYZ>
 __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __restrict__ pool, long long plane,
                                                             const RefConst* __restrict__ refs,
                                                             const PairConst* __restrict__ pairs, int n_ref, int n,
                                                             int W, int H, int max_chunks, int lambdaN,
-                                                            const unsigned* __restrict__ act, float* __restrict__ chk)
+                                                            const unsigned* __restrict__ act, float* __restrict__ chk,
+                                                            const KfMeta* __restrict__ meta, float* __restrict__ xyz)
 {
     const int b = blockIdx.x;
     const int i8 = b >> 3;
@@ -1041,6 +1065,7 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __rest
     if (!(lt_1em6(depthp)))
         out = inter_check_pixel(pool, plane, rc, pairs + (long long)ref * n, n, W, H, x, y, depthp, lambdaN);
     chk[o] = out;
+    if (XYZ) pointset_pixel(meta[rc.slot], x, y, out, xyz + o * 3);
 }
 
 // rho plane of the depth map -> checked plane
@@ -1121,25 +1146,8 @@ __global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict
     if (t >= rc.act_count) return;
     const unsigned xy = act[(long long)rc.slot * plane + t];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-    const KfMeta m = meta[rc.slot];
-    float Rwc[9], Ow[3], tcw[3] = {m.Tcw[3], m.Tcw[7], m.Tcw[11]};  // Twc, src/KeyFrame.cc:70-84
-    for (int i = 0; i < 3; i++)
-        for (int k = 0; k < 3; k++) Rwc[i * 3 + k] = m.Tcw[k * 4 + i];
-    mat3_vec(Rwc, tcw, Ow);
     const long long idx = (long long)rc.slot * plane + y * W + x;
-    float inv_d = src_base[idx * sstride];
-    float* o = xyz + idx * 3;
-    if (lt_1em6(inv_d)) {  // PM.cc:345
-        o[0] = 0.f;
-        o[1] = 0.f;
-        o[2] = 0.f;
-        return;
-    }
-    float Z = rcp_exact(inv_d);
-    float X = Z * ((float)x - m.cx) / m.fx;
-    float Y = Z * ((float)y - m.cy) / m.fy;
-#pragma unroll
-    for (int i = 0; i < 3; i++) o[i] = ((Rwc[i * 3 + 0] * X + Rwc[i * 3 + 1] * Y) + Rwc[i * 3 + 2] * Z) + (-Ow[i]) * 1.0f;
+    pointset_pixel(meta[rc.slot], x, y, src_base[idx * sstride], xyz + idx * 3);
 }
 
 // ---- single-thread kernels behind the per-pixel C entry points ------------------------------------------------

@@ -148,7 +148,7 @@ def allgather_depth(pool, first, count, group=None):
 def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None):
     """One pass of the hot path over this rank's keyframe block (what bench.py times and the
     multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
-    check (K4, snapshot form) -> point set (K5).
+    check (K4, snapshot form) + point set (K5; back-projected in the checking kernel).
 
     halo: boundary keyframes are reconstructed first; their maps travel to the adjacent ranks
     (point-to-point over xGMI) while the interior keyframes are reconstructed."""
@@ -166,5 +166,4 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None):
         eng.recon(own, nbrs, min_d, max_d)
         if world > 1:
             allgather_depth(pool, pl["first"], pl["count"], group)
-    eng.inter_check(own, nbrs, commit=False)
-    eng.pointset(own, source=1)
+    eng.inter_check_pointset(own, nbrs, commit=False)  # K4 with K5 riding along (PM.cc:300-306)

@@ -617,3 +617,47 @@ def test_tiny_and_odd_sizes(pkg, oracle, gpu_ok, W, H):
         assert_bit_equal(eng.download_checked(k), c, "%dx%d checked kf %d" % (W, H, k))
         assert_bit_equal(eng.download_pointset(k), oracle.pointset(okf[k], c), "%dx%d xyz kf %d" % (W, H, k))
     eng.close()
+
+
+def test_fused_inter_check_pointset(pkg, oracle, gpu_ok, seq_mid):
+    """sdm_inter_check_pointset == sdm_inter_check + sdm_pointset(source=1), on pipeline maps (one kernel) and on
+    uploaded maps (falls back to the two passes), snapshot and commit forms; and == the oracle"""
+    n = 7
+    seq = seq_mid
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    out = {}
+    for mode in ("separate", "fused"):
+        eng = make_engine(pkg, seq, n, with_pointset=True)
+        eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+        maps = {k: eng.download_depth(k) for k in refs}
+        if mode == "fused":
+            eng.inter_check_pointset(refs, nbrs)
+        else:
+            eng.inter_check(refs, nbrs)
+            eng.pointset(refs, source=1)
+        res = [(eng.download_checked(k), eng.download_pointset(k)) for k in refs]
+        # arbitrary (uploaded) maps: the generic path
+        for k in refs:
+            eng.upload_depth(k, maps[k][0], maps[k][1])
+        if mode == "fused":
+            eng.inter_check_pointset(refs[:3], nbrs[:3], commit=True)
+        else:
+            eng.inter_check(refs[:3], nbrs[:3], commit=True)
+            eng.pointset(refs[:3], source=1)
+        res2 = [(eng.download_checked(k), eng.download_pointset(k), eng.download_depth(k)[0]) for k in refs[:3]]
+        out[mode] = (res, res2, maps)
+        eng.close()
+    for k in refs:
+        assert_bit_equal(out["fused"][0][k][0], out["separate"][0][k][0], "checked kf %d" % k)
+        assert_bit_equal(out["fused"][0][k][1], out["separate"][0][k][1], "xyz kf %d" % k)
+    for k in range(3):
+        for i, what in enumerate(("checked", "xyz", "committed rho")):
+            assert_bit_equal(out["fused"][1][k][i], out["separate"][1][k][i], "uploaded maps, %s kf %d" % (what, k))
+    maps = out["fused"][2]
+    for k in refs[:4]:
+        c = oracle.inter_check(seq.okf[k], maps[k][0], [seq.okf[j] for j in nbrs[k]], [maps[j][0] for j in nbrs[k]],
+                               [maps[j][1] for j in nbrs[k]])
+        assert_bit_equal(out["fused"][0][k][0], c, "fused checked vs oracle kf %d" % k)
+        assert_bit_equal(out["fused"][0][k][1], oracle.pointset(seq.okf[k], c), "fused xyz vs oracle kf %d" % k)
+    assert sum(int((r[0] > 1e-6).sum()) for r in out["fused"][0]) > 500
