@@ -730,6 +730,9 @@ __device__ __forceinline__ float2 intra_check_pixel(const float2* __restrict__ i
 
 __device__ __forceinline__ float2 intra_grow_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c)
 {
+    // sigma_p == 0 (every pixel the pipeline left unsupported): ChiTest(.., sigma_p) is Delta^2/0 = Inf, or 0/0 = NaN
+    // when Delta = 0 -- never below 5.99, so nothing can grow here and the 3x3 gather is skipped
+    if (c.y == 0.0f) return c;
     float pjsj = 0.f, rsj = 0.f, smin = 0.f;  // GetFusion overload A, PM.cc:926-945
     int cnt = 0;
     float2 v[8];
