@@ -767,9 +767,13 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
         if (max_chunks == 0) continue;
         const int grid = 8 * ((max_chunks + 7) / 8) * count;
         if (check) {
-            HIP_TRY(hipMemsetAsync(c->scratch, 0, sizeof(float2) * c->P * count, c->stream));
+            // K2 writes every listed pixel of the scratch planes, and K3's list kernel substitutes zeros for
+            // neighbours outside the list instead of reading them, so the planes need no clearing -- unless the
+            // pass stands alone and the whole plane is copied back below
+            if (!grow) HIP_TRY(hipMemsetAsync(c->scratch, 0, sizeof(float2) * c->P * count, c->stream));
             hipLaunchKernelGGL(k_intra_list<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
-                               c->d_off, c->d_off + K, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act);
+                               c->d_off, c->d_off + K, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act,
+                               c->rec, c->H, c->dprm.lambdaG);
             HIP_TRY(hipGetLastError());
         } else {
             for (int r = 0; r < count; r++)
@@ -778,7 +782,8 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
         }
         if (grow) {
             hipLaunchKernelGGL(k_intra_list<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
-                               c->d_off + K, c->d_off, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act);
+                               c->d_off + K, c->d_off, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act,
+                               c->rec, c->H, c->dprm.lambdaG);
             HIP_TRY(hipGetLastError());
         } else {
             for (int r = 0; r < count; r++)

@@ -699,8 +699,9 @@ __global__ __launch_bounds__(BLOCK) void k_intra_grow(const float2* __restrict__
 // Inside SemiDenseRecon the map K2 reads was just written by K1: it is zero outside the keyframe's
 // active-pixel list, and K2/K3 only ever modify listed pixels (K2: pixels with rho > 1e-6; K3:
 // pixels with GradImg >= lambdaG).  So both passes run one thread per list entry with the 3x3
-// neighbourhood gathered straight from the (L2-resident) map; `dst` must be zero outside the list
-// (K2: a cleared scratch map, K3: the K1 map itself).  jobs: src/dst offsets per reference.
+// neighbourhood gathered straight from the (L2-resident) map.  K2 reads the K1 map (zero outside the list) and
+// writes the scratch plane at listed pixels only; K3 reads that plane at listed pixels only (a neighbour outside
+// the list is a zero by construction, see intra_grow_pixel<true>) and writes the K1 map.  jobs: src/dst offsets.
 __device__ __forceinline__ float2 intra_check_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c)
 {
     float pjsj = 0.f, rsj = 0.f, tmin = 0.f;  // GetFusion overload B streamed, PM.cc:947-970
@@ -728,7 +729,13 @@ __device__ __forceinline__ float2 intra_check_pixel(const float2* __restrict__ i
     return (cnt >= 3) ? make_float2(pjsj / rsj, tmin) : make_float2(0.f, 0.f);  // PM.cc:524-536
 }
 
-__device__ __forceinline__ float2 intra_grow_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c)
+// LISTED: `in` holds valid data only at pixels of the keyframe's active list (the scratch plane K2's list kernel
+// wrote); any other neighbour is a zero of the pipeline map and is substituted instead of read, so that plane never
+// has to be cleared.  rrec / H / lambdaG restate the list's membership rule (act_flag).
+template <bool LISTED>
+__device__ __forceinline__ float2 intra_grow_pixel(const float2* __restrict__ in, int W, int x, int y, float2 c,
+                                                   const float4* __restrict__ rrec = nullptr, int H = 0,
+                                                   float lambdaG = 0.f)
 {
     // sigma_p == 0 (every pixel the pipeline left unsupported): ChiTest(.., sigma_p) is Delta^2/0 = Inf, or 0/0 = NaN
     // when Delta = 0 -- never below 5.99, so nothing can grow here and the 3x3 gather is skipped
@@ -739,7 +746,11 @@ __device__ __forceinline__ float2 intra_grow_pixel(const float2* __restrict__ in
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         if (k == 4) continue;
-        v[k < 4 ? k : k - 1] = in[(y + k / 3 - 1) * W + x + (k % 3) - 1];
+        const int xn = x + (k % 3) - 1, yn = y + k / 3 - 1;
+        float2 t = make_float2(0.f, 0.f);
+        if (!LISTED || ((xn >= 2 && xn < W - 2 && yn >= 2 && yn < H - 2) && !(rrec[yn * W + xn].x < lambdaG)))
+            t = in[yn * W + xn];
+        v[k < 4 ? k : k - 1] = t;
     }
     const float rc = safe_rcp_sq(c.y);
 #pragma unroll
@@ -759,7 +770,8 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
                                                       const long long* __restrict__ src_off,
                                                       const long long* __restrict__ dst_off,
                                                       const RefConst* __restrict__ refs, int first, int n_ref, int W,
-                                                      int max_chunks, long long plane, const unsigned* __restrict__ act)
+                                                      int max_chunks, long long plane, const unsigned* __restrict__ act,
+                                                      const float4* __restrict__ rec, int H, float lambdaG)
 {
     const int b = blockIdx.x;
     const int i8 = b >> 3;
@@ -777,7 +789,8 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
     const float2 c = in[y * W + x];
     float2 o = c;
     if (GROW) {
-        if (lt_1em6(c.x)) o = intra_grow_pixel(in, W, x, y, c);  // PM.cc:560 (gradient gate = list)
+        if (lt_1em6(c.x))  // PM.cc:560 (gradient gate = list)
+            o = intra_grow_pixel<true>(in, W, x, y, c, rec + (long long)rc.slot * plane, H, lambdaG);
     } else {
         if (gt_1em6(c.x)) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
     }
