@@ -81,27 +81,40 @@ struct sdm_ctx {
     unsigned long long* d_sums = nullptr;
     float* d_small = nullptr;  // 16 floats of per-pixel results
 
-    // per-call tables: one packed device block + pinned host mirror, staged with a single copy.
-    // The pointers below are carved out of it per call; a call whose tables equal the previous call's
-    // (same slots, same constants, nothing re-uploaded since) reuses them without any copy or set-up kernel.
+    // per-call tables: one packed device block + pinned host mirror, staged with a single copy, and the
+    // RefConst/PairConst blocks built from it.  TABLE_SETS such sets are kept, each remembering the call it was
+    // staged for: a call whose tables equal a cached set's (same slots, same constants, nothing re-uploaded since)
+    // reuses that set without any copy, set-up kernel or host wait -- K1->K4->K5 of one step, and the boundary /
+    // interior / whole-block calls of the multi-GPU step, which alternate between three table sets.  The members
+    // below the array alias the set selected for the current call.
     int cap_refs = 0;
-    unsigned char *d_tab = nullptr, *h_tab = nullptr;
     size_t tab_bytes = 0;
-    int *d_ref_slots = nullptr, *d_nbr_slots = nullptr;
-    float *d_rot = nullptr, *d_mind = nullptr, *d_maxd = nullptr;
-    long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of n_ref: pool, scratch, record
     struct TableKey {
         bool valid = false, has_consts = false;
         int n_ref = 0, n = 0;
         unsigned long long epoch = 0;
         std::vector<int> refs, nbrs;
         std::vector<float> rot, mind, maxd;
-    } tkey;
+    };
+    static constexpr int TABLE_SETS = 4;
+    struct TableSet {
+        unsigned char *d_tab = nullptr, *h_tab = nullptr;
+        RefConst* d_refs = nullptr;
+        PairConst* d_pairs = nullptr;
+        TableKey key;
+        hipEvent_t free_ev = nullptr;  // the pinned block may be rewritten once this has passed
+        bool pending = false;
+        unsigned long long last_use = 0;
+    } sets[TABLE_SETS];
+    int cur_set = 0;
+    unsigned long long use_tick = 0;
+    unsigned char *d_tab = nullptr, *h_tab = nullptr;
+    int *d_ref_slots = nullptr, *d_nbr_slots = nullptr;
+    float *d_rot = nullptr, *d_mind = nullptr, *d_maxd = nullptr;
+    long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of n_ref: pool, scratch, record
     unsigned long long epoch = 1;  // bumped whenever poses, intrinsics, lists or slots change
     RefConst* d_refs = nullptr;
     PairConst* d_pairs = nullptr;
-    hipEvent_t tables_free = nullptr;
-    bool tables_pending = false;
 
     float2* h_f2 = nullptr;  // pinned interleave buffer, P elements
 
@@ -172,13 +185,37 @@ int check_slot(sdm_ctx* c, int slot, bool need_upload)
     return SDM_OK;
 }
 
+// the current set's pinned block is free for rewriting after this
 int wait_tables(sdm_ctx* c)
 {
-    if (c->tables_pending) {
-        HIP_TRY(hipEventSynchronize(c->tables_free));
-        c->tables_pending = false;
+    sdm_ctx::TableSet& s = c->sets[c->cur_set];
+    if (s.pending) {
+        HIP_TRY(hipEventSynchronize(s.free_ev));
+        s.pending = false;
     }
     return SDM_OK;
+}
+
+// make set `si` the current one and carve the packed block for a call of (n_ref, np)
+// packed layout (4-byte units): refs[n_ref] nbrs[np] rot[np] mind[n_ref] maxd[n_ref] | 8-byte: off[3*n_ref]
+size_t select_set(sdm_ctx* c, int si, int n_ref, size_t np)
+{
+    sdm_ctx::TableSet& s = c->sets[si];
+    c->cur_set = si;
+    c->d_tab = s.d_tab;
+    c->h_tab = s.h_tab;
+    c->d_refs = s.d_refs;
+    c->d_pairs = s.d_pairs;
+    size_t words = (size_t)n_ref * 3 + np * 2;
+    words = (words + 1) & ~(size_t)1;
+    c->h_off = reinterpret_cast<long long*>(c->h_tab + words * 4);
+    c->d_ref_slots = reinterpret_cast<int*>(c->d_tab);
+    c->d_nbr_slots = c->d_ref_slots + n_ref;
+    c->d_rot = reinterpret_cast<float*>(c->d_nbr_slots + np);
+    c->d_mind = c->d_rot + np;
+    c->d_maxd = c->d_mind + n_ref;
+    c->d_off = reinterpret_cast<long long*>(c->d_tab + words * 4);
+    return words;
 }
 
 int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
@@ -231,26 +268,41 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     if ((rc = sync_counts(c))) return rc;  // callers size their grids from h_act_count
 
     const size_t np = (size_t)n_ref * (size_t)n;
-    sdm_ctx::TableKey& k = c->tkey;
-    bool hit = k.valid && k.epoch == c->epoch && k.n_ref == n_ref &&
-               memcmp(k.refs.data(), ref_slots, sizeof(int) * n_ref) == 0;
-    if (hit && n > 0) hit = (k.n == n) && memcmp(k.nbrs.data(), nbr_slots, sizeof(int) * np) == 0;
-    if (hit && need_consts) {
-        hit = k.has_consts && memcmp(k.mind.data(), mind, sizeof(float) * n_ref) == 0 &&
-              memcmp(k.maxd.data(), maxd, sizeof(float) * n_ref) == 0;
-        if (hit) {
-            if (rot)
-                hit = memcmp(k.rot.data(), rot, sizeof(float) * np) == 0;
-            else
-                for (size_t i = 0; i < np && hit; i++) hit = (k.rot[i] == 0.0f);
+    auto matches = [&](const sdm_ctx::TableKey& k) {
+        bool hit = k.valid && k.epoch == c->epoch && k.n_ref == n_ref &&
+                   memcmp(k.refs.data(), ref_slots, sizeof(int) * n_ref) == 0;
+        if (hit && n > 0) hit = (k.n == n) && memcmp(k.nbrs.data(), nbr_slots, sizeof(int) * np) == 0;
+        if (hit && need_consts) {
+            hit = k.has_consts && memcmp(k.mind.data(), mind, sizeof(float) * n_ref) == 0 &&
+                  memcmp(k.maxd.data(), maxd, sizeof(float) * n_ref) == 0;
+            if (hit) {
+                if (rot)
+                    hit = memcmp(k.rot.data(), rot, sizeof(float) * np) == 0;
+                else
+                    for (size_t i = 0; i < np && hit; i++) hit = (k.rot[i] == 0.0f);
+            }
         }
+        return hit;
+    };
+    for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
+        if (!matches(c->sets[si].key)) continue;
+        // the carve-out follows the sizes the set was staged with (a key with n > 0 serves an n == 0 call too)
+        select_set(c, si, n_ref, (size_t)n_ref * (size_t)c->sets[si].key.n);
+        c->sets[si].last_use = ++c->use_tick;
+        return SDM_OK;
     }
-    if (hit) return SDM_OK;
-
-    if ((rc = wait_tables(c))) return rc;
-    // packed layout (4-byte units): refs[n_ref] nbrs[np] rot[np] mind[n_ref] maxd[n_ref] | 8-byte: off[3*n_ref]
-    size_t words = (size_t)n_ref * 3 + np * 2;
-    words = (words + 1) & ~(size_t)1;
+    int victim = 0;  // an empty set, else the least recently used one
+    for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
+        if (!c->sets[si].key.valid) {
+            victim = si;
+            break;
+        }
+        if (c->sets[si].last_use < c->sets[victim].last_use) victim = si;
+    }
+    const size_t words = select_set(c, victim, n_ref, np);
+    if ((rc = wait_tables(c))) return rc;  // only if that set was staged within the last few calls
+    sdm_ctx::TableKey& k = c->sets[victim].key;
+    k.valid = false;
     const size_t bytes = words * 4 + sizeof(long long) * 3 * (size_t)n_ref;
     if (bytes > c->tab_bytes) return fail(SDM_EINVAL, "table staging overflow");
     int* h_refs = reinterpret_cast<int*>(c->h_tab);
@@ -258,13 +310,6 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     float* h_rot = reinterpret_cast<float*>(h_nbrs + np);
     float* h_mind = h_rot + np;
     float* h_maxd = h_mind + n_ref;
-    c->h_off = reinterpret_cast<long long*>(c->h_tab + words * 4);
-    c->d_ref_slots = reinterpret_cast<int*>(c->d_tab);
-    c->d_nbr_slots = c->d_ref_slots + n_ref;
-    c->d_rot = reinterpret_cast<float*>(c->d_nbr_slots + np);
-    c->d_mind = c->d_rot + np;
-    c->d_maxd = c->d_mind + n_ref;
-    c->d_off = reinterpret_cast<long long*>(c->d_tab + words * 4);
     memcpy(h_refs, ref_slots, sizeof(int) * n_ref);
     if (np) memcpy(h_nbrs, nbr_slots, sizeof(int) * np);
     for (size_t i = 0; i < np; i++) h_rot[i] = rot ? rot[i] : 0.0f;
@@ -296,8 +341,9 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     k.rot.assign(h_rot, h_rot + np);
     k.mind.assign(h_mind, h_mind + n_ref);
     k.maxd.assign(h_maxd, h_maxd + n_ref);
-    HIP_TRY(hipEventRecord(c->tables_free, c->stream));  // the pinned block may be rewritten after this point
-    c->tables_pending = true;
+    HIP_TRY(hipEventRecord(c->sets[victim].free_ev, c->stream));  // the pinned block may be rewritten after this point
+    c->sets[victim].pending = true;
+    c->sets[victim].last_use = ++c->use_tick;
     return SDM_OK;
 }
 
@@ -492,8 +538,14 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
     const size_t np = (size_t)K * cfg->max_neighbours;
     c->tab_bytes = 4 * ((size_t)K * 3 + np * 2 + 2) + sizeof(long long) * 3 * (size_t)K;
-    if ((rc = dev_alloc(&c->d_tab, c->tab_bytes)) || (rc = host_alloc(&c->h_tab, c->tab_bytes))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_refs, K)) || (rc = dev_alloc(&c->d_pairs, np))) return bail(rc);
+    for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
+        sdm_ctx::TableSet& s = c->sets[si];
+        if ((rc = dev_alloc(&s.d_tab, c->tab_bytes)) || (rc = host_alloc(&s.h_tab, c->tab_bytes))) return bail(rc);
+        if ((rc = dev_alloc(&s.d_refs, K)) || (rc = dev_alloc(&s.d_pairs, np))) return bail(rc);
+        if (hipEventCreateWithFlags(&s.free_ev, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+    }
+    select_set(c, 0, 1, 0);
     if ((rc = host_alloc(&c->h_f2, (size_t)c->P))) return bail(rc);
     if ((rc = host_alloc(&c->h_act_count, (size_t)K))) return bail(rc);
     memset(c->h_act_count, 0, sizeof(int) * (size_t)K);
@@ -502,8 +554,6 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         if (hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming) != hipSuccess)
             return bail(fail(SDM_EHIP, "hipEventCreate failed"));
     }
-    if (hipEventCreateWithFlags(&c->tables_free, hipEventDisableTiming) != hipSuccess)
-        return bail(fail(SDM_EHIP, "hipEventCreate failed"));
 
     // zero-initialised maps, as a fresh KeyFrame's depth_map_/depth_sigma_/SemiDensePointSets_
     if (hipMemsetAsync(c->rec, 0, sizeof(float4) * c->P * K, c->stream) != hipSuccess ||
@@ -548,17 +598,20 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_sums);
     (void)hipFree(c->d_small);
     (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_tab);
-    (void)hipFree(c->d_refs);
-    (void)hipFree(c->d_pairs);
-    (void)hipHostFree(c->h_tab);
+    for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
+        sdm_ctx::TableSet& s = c->sets[si];
+        (void)hipFree(s.d_tab);
+        (void)hipFree(s.d_refs);
+        (void)hipFree(s.d_pairs);
+        (void)hipHostFree(s.h_tab);
+        if (s.free_ev) (void)hipEventDestroy(s.free_ev);
+    }
     (void)hipHostFree(c->h_f2);
     (void)hipHostFree(c->h_act_count);
     for (int b = 0; b < 2; b++) {
         (void)hipHostFree(c->h_im_stage[b]);
         if (c->stage_done[b]) (void)hipEventDestroy(c->stage_done[b]);
     }
-    if (c->tables_free) (void)hipEventDestroy(c->tables_free);
     for (auto& sp : c->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
@@ -1065,7 +1118,7 @@ static int intra_maps(sdm_ctx* c, float* rho, float* sigma, const float* grad, b
     if (rc) return rc;
     if ((rc = upload_f2(c, c->scratch, rho, sigma))) return rc;
     // private use of the staging block: [in, out, grad] offsets of one map; the cached tables are gone
-    c->tkey.valid = false;
+    c->sets[c->cur_set].key.valid = false;
     c->h_off = reinterpret_cast<long long*>(c->h_tab);
     c->d_off = reinterpret_cast<long long*>(c->d_tab);
     const int K = 1;
