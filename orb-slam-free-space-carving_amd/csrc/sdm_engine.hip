@@ -719,6 +719,7 @@ int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
     int rc = check_slot(c, slot, true);
     if (rc) return rc;
     if (!Tcw) return fail(SDM_EINVAL, "null pose");
+    if (memcmp(c->h_meta[slot].Tcw, Tcw, sizeof(float) * 12) == 0) return SDM_OK;  // unchanged: keep cached tables
     memcpy(c->h_meta[slot].Tcw, Tcw, sizeof(float) * 12);
     return push_meta(c, slot, true);
 }
