@@ -162,6 +162,12 @@ int build_active(sdm_ctx* c, int slot)
     HIP_TRY(hipMemcpyAsync(&c->h_act_count[slot], c->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost,
                            c->stream));
     c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
+    if (c->act_lambdaG[slot] == c->act_lambdaG[slot]) {
+        // the slot had a list under another lambdaG: its checked / xyz planes were written through that list and may
+        // be non-zero outside the new one
+        c->chk_sparse[slot] = 0;
+        c->xyz_sparse[slot] = 0;
+    }
     c->act_lambdaG[slot] = c->dprm.lambdaG;
     c->epoch++;
     return SDM_OK;

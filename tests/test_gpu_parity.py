@@ -661,3 +661,57 @@ def test_fused_inter_check_pointset(pkg, oracle, gpu_ok, seq_mid):
         assert_bit_equal(out["fused"][0][k][0], c, "fused checked vs oracle kf %d" % k)
         assert_bit_equal(out["fused"][0][k][1], oracle.pointset(seq.okf[k], c), "fused xyz vs oracle kf %d" % k)
     assert sum(int((r[0] > 1e-6).sum()) for r in out["fused"][0]) > 500
+
+
+def test_table_cache_alternating_calls(pkg, oracle, gpu_ok, seq_mid):
+    """the engine keeps several staged table sets keyed by the call's arguments: six different calls in rotation
+    (more than there are sets), with pose changes, an in-plane-rotation change and a parameter change in between,
+    must give exactly what a fresh engine gives for the same call"""
+    seq, n = seq_mid, 4
+    rng = np.random.default_rng(3)
+    eng = make_engine(pkg, seq, n, with_pointset=True)
+    all_k = list(range(seq.n_kf))
+    groups = [all_k[:3], all_k[3:6], all_k[1:5], all_k[::2], all_k[5:], all_k[2:4]]
+    poses = {k: seq.Tcw[k].copy() for k in all_k}
+    lam = 8.0
+
+    def fresh(refs, nbrs, rot, mind, maxd, state):
+        e2 = pkg.Engine(seq.W, seq.H, seq.n_kf, max_neighbours=n, with_pointset=True)
+        for k in all_k:
+            e2.upload_image(k, seq.im[k], seq.K, poses[k])
+            if k not in refs:  # the inter-keyframe check reads the neighbours' current maps
+                e2.upload_depth(k, state[k][0], state[k][1])
+        e2.set_params(lambdaG=lam)
+        e2.recon(refs, nbrs, mind, maxd, rot=rot)
+        e2.inter_check_pointset(refs, nbrs)
+        out = [(e2.download_depth(k), e2.download_checked(k), e2.download_pointset(k)) for k in refs]
+        e2.close()
+        return out
+
+    for it in range(14):
+        refs = groups[it % len(groups)]
+        nbrs = [[j for j in all_k if j != k][(it // 6):(it // 6) + n] for k in refs]
+        rot = np.zeros((len(refs), n), np.float32)
+        if it % 4 == 3:
+            rot[0, 0] = 7.5  # same slots, other constants: must not hit a cached set
+        mind, maxd = seq.min_depth * (1.0 + 0.01 * (it % 3)), seq.max_depth
+        if it == 5:  # a pose moves (bundle adjustment): every cached table is stale
+            poses[2] = poses[2].copy()
+            poses[2][0, 3] += np.float32(0.003)
+            eng.set_pose(2, poses[2])
+        if it == 9:
+            lam = 12.0
+            eng.set_params(lambdaG=lam)
+        check = it in (0, 4, 5, 6, 7, 9, 10, 13)  # a fresh engine is slow to set up: check a subset of the rotation
+        state = {k: eng.download_depth(k) for k in all_k} if check else None
+        eng.recon(refs, nbrs, mind, maxd, rot=rot)
+        eng.inter_check_pointset(refs, nbrs)
+        got = [(eng.download_depth(k), eng.download_checked(k), eng.download_pointset(k)) for k in refs]
+        if check:
+            want = fresh(refs, nbrs, rot, mind, maxd, state)
+            for (g, w, k) in zip(got, want, refs):
+                assert_bit_equal(g[0][0], w[0][0], "it %d rho kf %d" % (it, k))
+                assert_bit_equal(g[0][1], w[0][1], "it %d sigma kf %d" % (it, k))
+                assert_bit_equal(g[1], w[1], "it %d checked kf %d" % (it, k))
+                assert_bit_equal(g[2], w[2], "it %d xyz kf %d" % (it, k))
+    eng.close()
