@@ -3,6 +3,7 @@ forward baselines (|a/b| > 4 gate, epipoles inside the image), per-keyframe intr
 rotations and depth priors (including swapped / negative / huge bounds), textured and noise images.
 Everything must stay bit-identical, including the NaN/Inf propagation rules of the reference."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -54,8 +55,13 @@ def make_case(rng, oracle, W, H, n_kf, mode):
     return dict(im=ims, K=Ks, Tcw=Ts, okf=okf, derived=derived)
 
 
-@pytest.mark.parametrize("mode,seed", [("small", 1), ("small", 2), ("large", 3), ("large", 4), ("forward", 5),
-                                       ("vertical", 6), ("noise", 7), ("small", 8), ("large", 9), ("forward", 10)])
+_EXTRA = int(os.environ.get("SDM_FUZZ_GEOM", "0"))  # deeper one-off runs: that many more seeds per mode
+_CASES = [("small", 1), ("small", 2), ("large", 3), ("large", 4), ("forward", 5), ("vertical", 6), ("noise", 7),
+          ("small", 8), ("large", 9), ("forward", 10)]
+_CASES += [(mode, 100 + i) for i in range(_EXTRA) for mode in ("small", "large", "forward", "vertical", "noise")]
+
+
+@pytest.mark.parametrize("mode,seed", _CASES)
 def test_fuzz_whole_path(pkg, oracle, gpu_ok, mode, seed):
     rng = np.random.default_rng(1000 + seed)
     W, H, n_kf, n = 72, 56, 7, 5
