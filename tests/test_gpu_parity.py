@@ -3,6 +3,8 @@ oracle on the same seeded inputs.  Bar: BIT-EXACT for every output -- support ma
 checked rho and the point set -- because both sides evaluate the same IEEE operation sequence with
 FMA contraction off (the stated float tolerance of BASELINE.json is therefore 0 ulp here; the
 full-size tests in test_gpu_fullsize.py state their own tolerances)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -585,7 +587,12 @@ def test_flat_images_have_no_work(pkg, oracle, gpu_ok):
     eng.close()
 
 
-@pytest.mark.parametrize("W,H", [(8, 8), (9, 17), (131, 67), (64, 8)])
+_SIZE_RNG = np.random.default_rng(99)
+_SIZES = [(8, 8), (9, 17), (131, 67), (64, 8)] + [
+    (int(_SIZE_RNG.integers(8, 300)), int(_SIZE_RNG.integers(8, 200))) for _ in range(int(os.environ.get("SDM_FUZZ_SIZES", "0")))]
+
+
+@pytest.mark.parametrize("W,H", _SIZES)
 def test_tiny_and_odd_sizes(pkg, oracle, gpu_ok, W, H):
     """the smallest image the engine accepts and odd sizes: whole path against the oracle (noise images so that
     the gradient gate passes; any hypotheses that survive must agree)"""
