@@ -3,20 +3,29 @@
 
 One "step" = one pass of the whole path over this rank's block of keyframes:
   SemiDenseRecon (epipolar search + fusion + intra-keyframe check/grow, PM.cc:137-256)
-  -> [N>1: RCCL all-gather of the per-keyframe {rho,sigma} maps]
+  -> [N>1: exchange of the per-keyframe {rho,sigma} maps over RCCL: halo point-to-point or all-gather]
   -> InterKeyFrameDepthChecking (PM.cc:628-799) -> UpdateSemiDensePointSet (PM.cc:337-367)
 with every input already resident in HBM (search records packed before the timed region).
 
-Workload at N=1: BASELINE.json configs[1] -- 640x480, 64 keyframes x 20 covisible neighbours,
-synthetic gradient images.  Weak scaling: every rank owns --kfs keyframes of one N*kfs sequence.
+`value` is measured on BASELINE.json configs[1] -- 640x480, 64 keyframes x 20 covisible neighbours,
+synthetic gradient images.  At N=1 the same JSON line carries `extra_configs`: the north_star's target
+case (640x480 x 256 keyframes, N=20) and configs[2] (1280x720 x 256 keyframes, N=7), each with its own
+ms_per_step, K1 roofline and mean scan length.  Weak scaling: every rank owns --kfs keyframes of one
+N*kfs sequence (--independent: one separate sequence per GPU, configs[4]).
+
+`python bench.py --gpus N` with N>1 starts its own `torch.distributed.run` child (before anything
+touches the GPU) when it was not launched by one; the line printed is the child's.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_search_fuse, HIP events on the
 engine's stream, algorithmic bytes P*(17+9N) per keyframe) and `cpu_baseline` (the CPU oracle
 timed on this box's host cores on a bounded sample; a reported baseline, not the target).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEEDS = {"480p": 0x5EED0002, "720p": 0x5EED0003, "1080p": 0x5EED0004}
+BASELINE_CONFIG = {("480p", 64, 20): "BASELINE.json configs[1]",
+                   ("480p", 256, 20): "north_star target case",
+                   ("720p", 256, 7): "BASELINE.json configs[2]",
+                   ("480p", 8, 7): "BASELINE.json configs[0] geometry"}
 
 
 def parse():
@@ -37,26 +51,212 @@ def parse():
     ap.add_argument("--disparity", type=float, default=2.6, help="adjacent-keyframe disparity (px): scan-length knob")
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
-                    help="N>1 exchange of {rho,sigma} maps between K3 and K4 (shard.py)")
+                    help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with "
+                         "(the other form is timed too and reported under exchange_ms_per_step)")
+    ap.add_argument("--transport", default="native", choices=["native", "torch"],
+                    help="N>1: RCCL called by the engine's C ABI (sdm_exchange_*) or torch.distributed on the pool tensor")
+    ap.add_argument("--independent", action="store_true",
+                    help="N>1: one independent sequence per GPU, no exchange (BASELINE.json configs[4])")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 from a bare shell: become the parent of `python -m torch.distributed.run ... bench.py`.
+    Nothing in this process has touched the GPU (torch is not even imported yet); the child is a child
+    process, never an exec."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def source_hash():
+    """hash of the kernel sources: ties a committed PMC traffic figure to the build it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "orb-slam-free-space-carving_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload_name(W, H, kfs, N, res, independent=False):
+    tag = BASELINE_CONFIG.get((res, kfs, N))
+    s = "%dx%d, %d keyframes/GPU x %d covisible neighbours, synthetic gradient images" % (W, H, kfs, N)
+    if independent:
+        s += ", one independent sequence per GPU (BASELINE.json configs[4])"
+    return s + (" (%s)" % tag if tag and not independent else "")
+
+
+class Workload:
+    """One resident workload on this rank: scene, plan, engine, uploaded keyframes."""
+
+    def __init__(self, pkg, torch, res, kfs, N, disparity, world, rank, local_rank, independent=False,
+                 keep_images=0):
+        synth, shard = pkg.synth, pkg.shard
+        self.pkg, self.torch = pkg, torch
+        cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[res]
+        self.res, self.W, self.H, self.N, self.kfs = res, cam["W"], cam["H"], N, kfs
+        self.P = self.W * self.H
+        self.independent = independent
+        if independent:  # configs[4]: every GPU has its own sequence (seeds 0x5EED0050..57), no exchange
+            self.n_total = kfs
+            self.scene = synth.Scene(cam, 0x5EED0050 + rank, disparity_px=disparity)
+            self.pl = shard.plan(kfs, 1, 0, N, self.scene.neighbours)
+        else:
+            self.n_total = kfs * world
+            self.scene = synth.Scene(cam, SEEDS[res], disparity_px=disparity)
+            self.pl = shard.plan(self.n_total, world, rank, N, self.scene.neighbours)
+        pl = self.pl
+        self.min_d, self.max_d = self.scene.depth_prior()
+        # engine on torch's current stream; depth pool owned by torch (the torch transport exchanges it in place)
+        self.pool = torch.zeros((pl["n_slots"], self.H, self.W, 2), dtype=torch.float32, device="cuda")
+        self.eng = pkg.Engine(self.W, self.H, pl["n_slots"], max_neighbours=N, device=local_rank,
+                              batch_capacity=min(kfs, 64), with_pointset=True, ext_depth_pool=self.pool.data_ptr(),
+                              stream=torch.cuda.current_stream().cuda_stream)
+        self.K = self.scene.K()
+        self.images = {}
+        t0 = time.time()
+        for k in pl["inputs"]:  # own block + input halo, rendered on the GPU, packed into search records
+            im, _ = self.scene.render(k, device="cuda")
+            torch.cuda.synchronize()
+            self.eng.upload_image_device(pl["slot"][k], im.data_ptr(), self.K, self.scene.Tcw(k))
+            if k < keep_images:
+                self.images[k] = im.cpu().numpy()
+        self.t_gen = time.time() - t0
+
+    def step(self, exchange, transport, group=None):
+        self.pkg.shard.pipeline_step(self.eng, self.pool, self.pl, self.min_d, self.max_d, exchange, group, transport)
+
+    def scan_stats(self):
+        eng, pl = self.eng, self.pl
+        eng.enable_stats(True)
+        eng.get_stats(reset=True)
+        eng.search_fuse(pl["own_slots"], pl["nbr_slots"], self.min_d, self.max_d)
+        st = eng.get_stats()
+        eng.enable_stats(False)
+        return st
+
+    def close(self):
+        self.eng.close()
+        self.pool = None
+        self.torch.cuda.empty_cache()
+
+
+def timed(wl, steps, warmup, barrier, exchange, transport):
+    """W warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides."""
+    for _ in range(warmup):
+        wl.step(exchange, transport)
+    wl.eng.enable_timing(True)
+    wl.eng.get_timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step(exchange, transport)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = wl.eng.get_timing(reset=True)
+    wl.eng.enable_timing(False)
+    return dt, timing
+
+
+def roofline(wl, timing, steps, traffic):
+    """K1's roofline record.  `achieved` = ALGORITHMIC bytes (P*(17+9N) per reference
+    keyframe x the keyframes one launch covers) / the launch's HIP-event duration; `traffic` = HBM-side bytes
+    per launch from the PMC run of the same build and workload (null otherwise); hbm_GBs = traffic / duration."""
+    k1_ms, k1_n = timing["search_fuse"]
+    k1_avg_ms = k1_ms / max(k1_n, 1)
+    k1_bytes = wl.P * (17 + 9 * wl.N) * len(wl.pl["own"]) * steps / max(k1_n, 1)
+    achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
+    out = {
+        "bound": "hbm", "kernel": "k_search_fuse",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "launch_ms": round(k1_avg_ms, 4), "launches": k1_n,
+        "algorithmic_bytes_per_launch": k1_bytes,
+        # what the counters say limits the kernel (profiles/, DESIGN.md §5): vector-instruction issue, not HBM
+        "limiter": "valu-issue",
+    }
+    if traffic:
+        out["hbm_GBs"] = round(traffic / (k1_avg_ms * 1e-3) / 1e9, 1)
+        out["hbm_frac"] = round(out["hbm_GBs"] / HBM_PEAK_GBS, 4)
+        out["traffic_source"] = "profiles/ PMC run (rocprofv3 --pmc, TCC_EA0 request counters) of this build and workload"
+    return out, k1_avg_ms
+
+
+def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps):
+    """HBM-side bytes of one k_search_fuse launch from a committed PMC run (tools/pmc.sh: rocprofv3 cannot
+    run inside bench.py).  Only a file whose workload AND kernel-source hash match this build is used."""
+    src = source_hash()
+    pdir = os.path.join(ROOT, "profiles")
+    if k1_launches != steps or not os.path.isdir(pdir):  # profiled with one launch per step (single GPU)
+        return None
+    for f in sorted(os.listdir(pdir), reverse=True):
+        if not (f.endswith(".json") and "traffic" in f):
+            continue
+        try:
+            t = json.load(open(os.path.join(pdir, f)))
+        except ValueError:
+            continue
+        w = t.get("workload", {})
+        if t.get("src_hash") == src and \
+                (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity")) == (res, kfs, nbrs, disparity):
+            return t["traffic_bytes_per_launch"]
+    return None
+
+
+def scan_record(stats, k1_avg_ms):
+    return {
+        "searches": stats["searches"],
+        "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
+        "gate_pass": stats["gate_pass"], "hypotheses": stats["hypotheses"], "fused_pixels": stats["fused"],
+        "Mhyp_per_s": round(stats["searches"] / (k1_avg_ms * 1e-3) / 1e6, 1),
+    }
+
+
+def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier):
+    """one more single-GPU BASELINE workload, measured the same way as the headline one"""
+    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank)
+    stats = wl.scan_stats()
+    dt, timing = timed(wl, steps, warmup, barrier, "halo", "torch")
+    rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps))
+    out = {
+        "workload": workload_name(wl.W, wl.H, kfs, N, res),
+        "value": round(wl.P * wl.n_total * steps / dt / 1e6, 2), "unit": "Mpix*KF/s",
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+        "keyframes_total": wl.n_total, "neighbours": N,
+        "stage_ms_per_step": {s: round(v[0] / steps, 4) for s, v in timing.items()},
+        "roofline": rf,
+        "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
+        "scan": scan_record(stats, k1_avg),
+    }
+    wl.close()
+    return out
 
 
 def main():
     args = parse()
-    import numpy as np
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as dist
     import sdm_pkg
 
     pkg = sdm_pkg.load()
-    synth, shard = pkg.synth, pkg.shard
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     # SDM_BENCH_REHEARSE=1: every rank on GPU 0 with a gloo group and a host-staged exchange -- a dry run of the
@@ -65,86 +265,66 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    transport = args.transport
+    rccl_world = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            transport = "torch"  # RCCL refuses two ranks on one device
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+            rccl_world = dist.get_world_size()
 
-    cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[args.res]
-    W, H, N = cam["W"], cam["H"], args.nbrs
-    P = W * H
-    n_total = args.kfs * world
-    seed = {"480p": 0x5EED0002, "720p": 0x5EED0003, "1080p": 0x5EED0004}[args.res]
-    scene = synth.Scene(cam, seed, disparity_px=args.disparity)
-    pl = shard.plan(n_total, world, rank, N, scene.neighbours)
-    own, nbrs = pl["own"], pl["nbrs"]
-    min_d, max_d = scene.depth_prior()
-
-    # ---- engine on torch's current stream; depth pool owned by torch so RCCL gathers it in place
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch/RCCL and the engine
     torch.cuda.set_stream(stream)
-    pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32, device="cuda")
-    eng = pkg.Engine(W, H, n_total, max_neighbours=N, device=local_rank, batch_capacity=min(args.kfs, 64),
-                     with_pointset=True, ext_depth_pool=pool.data_ptr(), stream=stream.cuda_stream)
-    arch = eng.arch()
-    K = scene.K()
-    images = {}
-    t0 = time.time()
-    for k in pl["inputs"]:  # own block + input halo, rendered on the GPU, packed into search records
-        im, _ = scene.render(k, device="cuda")
-        torch.cuda.synchronize()
-        eng.upload_image_device(k, im.data_ptr(), K, scene.Tcw(k))
-        if rank == 0 and k < args.cpu_kfs + 2 * N:
-            images[k] = im.cpu().numpy()
-    t_gen = time.time() - t0
-    # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as
-    # HOST gray images through sdm_upload_image (H2D copy + device pre-pass + record packing)
-    t_h2d = None
-    if rank == 0 and world == 1 and images:
-        ks = sorted(images)[:16]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in ks:
-            eng.upload_image(k, images[k], K, scene.Tcw(k))
-        eng.synchronize()
-        t_h2d = (time.perf_counter() - t0) / len(ks)
-
-    def step():
-        shard.pipeline_step(eng, pool, pl, min_d, max_d, args.exchange)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- scan statistics (untimed counting variant of K1) ------------------------------------------
-    stats = None
-    if not args.no_stats:
-        eng.enable_stats(True)
-        eng.get_stats(reset=True)
-        eng.search_fuse(own, nbrs, min_d, max_d)
-        stats = eng.get_stats()
-        eng.enable_stats(False)
+    wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
+                  independent=args.independent,
+                  keep_images=(args.cpu_kfs + 2 * args.nbrs) if (rank == 0 and world == 1) else 0)
+    eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
+    n_total = wl.n_total * (world if args.independent else 1)
+    arch = eng.arch()
+    exchanging = world > 1 and not args.independent
+    if exchanging and transport == "native":
+        pkg.shard.setup_native_comm(eng)  # the engine's own RCCL communicator (include/sdm_c.h sdm_comm_init)
+        rccl_world = eng.comm_info()[0]
 
-    for _ in range(args.warmup):
-        step()
-    eng.enable_timing(True)
-    eng.get_timing(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timing = eng.get_timing(reset=True)
-    eng.enable_timing(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as
+    # HOST gray images through sdm_upload_image (H2D copy + device pre-pass + record packing)
+    t_h2d = None
+    if rank == 0 and world == 1 and wl.images:
+        ks = sorted(wl.images)[:16]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in ks:
+            eng.upload_image(pl["slot"][k], wl.images[k], wl.K, wl.scene.Tcw(k))
+        eng.synchronize()
+        t_h2d = (time.perf_counter() - t0) / len(ks)
+
+    stats = None if args.no_stats else wl.scan_stats()  # untimed counting variant of K1
+
+    def reduce_max(dt):
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
+
+    dt, timing = timed(wl, args.steps, args.warmup, barrier, args.exchange, transport)
+    dt = reduce_max(dt)
+    exchange_ms = None
+    if exchanging:  # the other exchange form, same K steps, so the line carries both
+        other = "allgather" if args.exchange == "halo" else "halo"
+        dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
+        dt2 = reduce_max(dt2)
+        exchange_ms = {args.exchange: round(dt / args.steps * 1e3, 4), other: round(dt2 / args.steps * 1e3, 4)}
 
     if rank != 0:
         eng.close()
@@ -154,12 +334,14 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = P * n_total * args.steps / dt / 1e6
-    k1_ms, k1_n = timing["search_fuse"]
-    # algorithmic bytes of k_search_fuse (P*(17+9N) per reference keyframe) over the
-    # keyframes one launch covers; a step may split its keyframes over 2 launches (boundary/interior)
-    k1_avg_ms = k1_ms / max(k1_n, 1)
-    k1_bytes = P * (17 + 9 * N) * len(own) * args.steps / max(k1_n, 1)
-    achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
+    rf, k1_avg_ms = roofline(wl, timing, args.steps,
+                             committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps)
+                             if world == 1 else None)
+    if not exchanging:
+        xdesc = "no exchange (%s)" % ("1 GPU" if world == 1 else "independent sequences")
+    else:
+        xdesc = "%s exchange of {rho,sigma} maps over RCCL (%s)" % (
+            args.exchange, "engine C ABI sdm_exchange_*" if transport == "native" else "torch.distributed")
     out = {
         "metric": "Mpix*KF/s fused (%dx%dxN_KF)" % (W, H),
         "value": round(value, 2),
@@ -174,96 +356,83 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%dx%d, %d keyframes/GPU x %d covisible neighbours, synthetic gradient images "
-                        "(BASELINE.json configs[1])" % (W, H, args.kfs, N),
-            "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" %
-                      ("no exchange (1 GPU)" if world == 1 else args.exchange + " exchange of {rho,sigma} maps (RCCL)"),
+            "workload": workload_name(W, H, args.kfs, N, args.res, args.independent),
+            "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" % xdesc,
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
-            "parallelism": "keyframe-block x%d" % world, "arch": arch,
+            "parallelism": ("independent x%d" if args.independent else "keyframe-block x%d") % world, "arch": arch,
+            "exchange": (args.exchange if exchanging else None),
+            "transport": (transport if exchanging else None),
+            "rccl_world_size": rccl_world,
+            "slots_per_rank": pl["n_slots"],
         },
         "stage_ms_per_step": {s: round(v[0] / args.steps, 4) for s, v in timing.items()},
-        "roofline": {
-            "bound": "hbm", "kernel": "k_search_fuse",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": k1_traffic(args, len(own), k1_n, args.steps),
-            "launch_ms": round(k1_avg_ms, 4), "launches": k1_n,
-            "algorithmic_bytes_per_launch": k1_bytes,
-        },
+        "roofline": rf,
     }
+    if exchange_ms:
+        out["exchange_ms_per_step"] = exchange_ms
     if rehearse:
         out["rehearsal"] = "all ranks on GPU 0, gloo, host-staged exchange: control-flow dry run, not a measurement"
     if stats:
-        out["scan"] = {
-            "searches": stats["searches"], "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
-            "gate_pass": stats["gate_pass"], "hypotheses": stats["hypotheses"], "fused_pixels": stats["fused"],
-            "Mhyp_per_s": round(stats["searches"] / (k1_avg_ms * 1e-3) / 1e6, 1),
-        }
+        out["scan"] = scan_record(stats, k1_avg_ms)
 
     # ---- CPU baseline: the oracle (a port; the reference itself cannot be built) on a bounded sample
     if args.cpu_kfs > 0 and world == 1:  # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H)
-    out["gen_s"] = round(t_gen, 2)
+        out["cpu_baseline"] = cpu_baseline(args, wl)
+    out["gen_s"] = round(wl.t_gen, 2)
     if t_h2d is not None:
         out["host_upload_ms_per_keyframe"] = round(t_h2d * 1e3, 4)
-        out["value_pcie_inclusive"] = round(P * n_total / (dt / args.steps + t_h2d * len(own)) / 1e6, 2)
-    print(json.dumps(out), flush=True)  # the result line first; teardown cannot lose it
-    eng.close()
+        out["value_pcie_inclusive"] = round(P * n_total / (dt / args.steps + t_h2d * len(pl["own"])) / 1e6, 2)
+
+    # ---- the other single-GPU BASELINE workloads, each measured like the headline one ----------------------
+    if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs) == ("480p", 64, 20):
+        wl.close()
+        extra = []
+        for (res, kfs, nb) in (("480p", 256, 20), ("720p", 256, 7)):
+            try:
+                extra.append(run_extra(pkg, torch, res, kfs, nb, args.disparity, max(5, args.steps // 2), 2,
+                                       local_rank, barrier))
+            except Exception as e:  # the headline line must survive a failing extra
+                extra.append({"workload": "%s x %d KF x N=%d" % (res, kfs, nb), "error": repr(e)})
+        out["extra_configs"] = extra
+    else:
+        eng.close()
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def k1_traffic(args, n_own, k1_launches, steps):
-    """HBM-side bytes of one k_search_fuse launch, from the committed PMC run of the same workload
-    (profiles/r01_traffic.json, produced by tools/pmc.sh: rocprofv3 cannot run inside bench.py).  null
-    when this run's workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    t = json.load(open(path))
-    w = t.get("workload", {})
-    if (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity")) != (args.res, args.kfs, args.nbrs, args.disparity):
-        return None
-    if k1_launches != steps:  # profiled with one launch per step (single GPU)
-        return None
-    return t["traffic_bytes_per_launch"]
-
-
-def cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H):
+def cpu_baseline(args, wl):
     """Times oracle/pm_oracle.c (checker + CPU baseline ONLY; never on the product path) on the
-    first cpu_kfs keyframes of the same workload, same stages as the GPU step: (i) 1 thread = the
-    reference's effective behaviour (its OpenMP pragmas are inert), (ii) OpenMP on
-    all host cores (what PM.cc:197's pragma intends)."""
+    first cpu_kfs keyframes of the same workload, same stages as the GPU step:
+      (i)  1 thread = the reference's effective behaviour (its OpenMP pragmas are inert, SURVEY.md §2);
+      (ii) all host cores, the rows of ALL sample keyframes shared out at once (pmo_*_batch: collapse over
+           (keyframe,row), no Python in the loop) -- what PM.cc:197's pragma intends, at its best."""
     import ctypes
+    import platform
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pm_oracle
+    eng, scene, images, N, pl = wl.eng, wl.scene, wl.images, wl.N, wl.pl
     out_dir = os.path.join(ROOT, "gpurun_out", "_oracle_build")
     ref = pm_oracle.Oracle("omp", out_dir=out_dir)  # -O3 -march=native -fopenmp, built on THIS box
     ncores = ref.num_threads()
-    sample = [k for k in range(args.cpu_kfs) if all(j in images for j in scene.neighbours(k, n_total, N))]
-    need = sorted(set(sample) | {j for k in sample for j in scene.neighbours(k, n_total, N)})
-    kf, gpu_maps = {}, {}
+    sample = [k for k in range(args.cpu_kfs) if all(j in images for j in scene.neighbours(k, wl.n_total, N))]
+    need = sorted(set(sample) | {j for k in sample for j in scene.neighbours(k, wl.n_total, N)})
+    idx = {k: i for i, k in enumerate(need)}
+    kfs, gpu_rho, gpu_sig = [], [], []
     for k in need:
         g, t, s = ref.gradient_prepass(images[k])
-        kf[k] = ref.keyframe(images[k], g, t, s, scene.K(), scene.Tcw(k))
-        gpu_maps[k] = eng.download_depth(k)  # neighbours' finished maps for the inter-keyframe check
+        kfs.append(ref.keyframe(images[k], g, t, s, scene.K(), scene.Tcw(k)))
+        r, sg = eng.download_depth(pl["slot"][k])  # neighbours' finished maps for the inter-keyframe check
+        gpu_rho.append(r)
+        gpu_sig.append(sg)
+    ref_idx = [idx[k] for k in sample]
+    nbr_idx = [[idx[j] for j in scene.neighbours(k, wl.n_total, N)] for k in sample]
 
     def run():
-        maps, chk = {}, {}
-        st_tot = dict(searches=0, candidates=0)
-        for k in sample:
-            nb = scene.neighbours(k, n_total, N)
-            r, s, st = ref.semi_dense_recon(kf[k], [kf[j] for j in nb], None, min_d, max_d)
-            maps[k] = (r, s)
-            st_tot["searches"] += st["searches"]
-            st_tot["candidates"] += st["candidates"]
-        for k in sample:
-            nb = scene.neighbours(k, n_total, N)
-            chk[k] = ref.inter_check(kf[k], maps[k][0], [kf[j] for j in nb], [gpu_maps[j][0] for j in nb],
-                                     [gpu_maps[j][1] for j in nb])
-            ref.pointset(kf[k], chk[k])
-        return maps, chk, st_tot
+        rho, sigma, st = ref.recon_batch(kfs, ref_idx, nbr_idx, wl.min_d, wl.max_d)
+        chk, _ = ref.inter_pointset_batch(kfs, ref_idx, nbr_idx, gpu_rho, gpu_sig, rho)
+        return rho, sigma, chk, st
 
     try:
         omp = ctypes.CDLL("libgomp.so.1")
@@ -271,7 +440,7 @@ def cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H):
     except OSError:
         omp = None
     t0 = time.perf_counter()
-    maps, chk, st = run()
+    rho, sigma, chk, st = run()
     t1 = time.perf_counter() - t0
     tn = t1
     if omp is not None:
@@ -281,20 +450,30 @@ def cpu_baseline(args, pkg, eng, scene, images, n_total, N, min_d, max_d, W, H):
         tn = time.perf_counter() - t0
     # live parity check of the GPU result against the oracle on the sample (depth L1 vs ref)
     l1, nmask, mism = 0.0, 0, 0
-    for k in sample:
-        for got, want in ((gpu_maps[k][0], maps[k][0]), (eng.download_checked(k), chk[k])):
+    for i, k in enumerate(sample):
+        for got, want in ((gpu_rho[idx[k]], rho[i]), (eng.download_checked(pl["slot"][k]), chk[i])):
             m = (want > 1e-6)
             mism += int(((got > 1e-6) != m).sum())
             l1 += float(np.abs(got[m] - want[m]).sum())
             nmask += int(m.sum())
-    px = W * H * len(sample)
+    px = wl.W * wl.H * len(sample)
+    cpu_model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": round(px / t1 / 1e6, 3), "unit": "Mpix*KF/s", "cores": 1, "kind": "port",
         "sample": "same stages (K1-K5) on the first %d keyframes of the same workload, oracle/pm_oracle.c "
                   "-O3 -march=native, 1 thread (the reference's OpenMP pragmas are inert)" % len(sample),
         "seconds": round(t1, 2),
+        "cpu_model": cpu_model,
         "all_cores": {"value": round(px / tn / 1e6, 3), "cores": ncores if omp is not None else 1,
-                      "seconds": round(tn, 2)},
+                      "seconds": round(tn, 2),
+                      "schedule": "OpenMP dynamic over (keyframe,row) of the whole sample, all stages in C"},
         "mean_candidates_per_search": round(st["candidates"] / max(st["searches"], 1), 3),
         "parity_on_sample": {"mask_mismatches": mism, "depth_L1": (l1 / max(nmask, 1)), "pixels": nmask},
     }

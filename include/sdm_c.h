@@ -31,6 +31,7 @@ extern "C" {
 #define SDM_EHIP 2     /* HIP runtime error (text in sdm_last_error) */
 #define SDM_ENODEV 3   /* no usable GPU */
 #define SDM_ESTATE 4   /* slot not uploaded / stage not run yet */
+#define SDM_ECOMM 5    /* RCCL error or library not loadable (text in sdm_last_error) */
 
 #define SDM_MAX_NEIGHBOURS 64
 
@@ -113,6 +114,11 @@ int sdm_recon(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *n
 int sdm_inter_check(sdm_ctx *ctx, int n_ref, const int *ref_slots, int n, const int *nbr_slots,
                     int commit);
 
+/* Precondition (the reference's gate at PM.cc:292-298: the keyframe and ALL its neighbours have
+ * semidense_flag_ set): every reference and neighbour slot must hold a depth map -- produced by sdm_recon /
+ * sdm_search_fuse, restored by sdm_upload_depth, received by an sdm_exchange_* call, or declared with
+ * sdm_assume_pipeline_maps / sdm_mark_depth_present.  Otherwise SDM_ESTATE. */
+
 /* ---- UpdateSemiDensePointSet, PM.h:88 / PM.cc:337-367 ----------------------------------------- */
 /* source: 0 = depth map, 1 = checked plane.  Needs with_pointset. */
 int sdm_pointset(sdm_ctx *ctx, int n_ref, const int *ref_slots, int source);
@@ -134,6 +140,42 @@ void *sdm_depth_pool_ptr(sdm_ctx *ctx);
  * set {inset pixels with GradImg >= lambdaG} -- true for every map SemiDenseRecon produced, e.g. maps
  * restored through sdm_upload_depth or received by an all-gather.  Lets K2-K4 use their list kernels. */
 int sdm_assume_pipeline_maps(sdm_ctx *ctx, int n, const int *slots);
+
+/* Maps written into an ext_depth_pool from outside the engine (the host framework's own collective):
+ * marks the slots as holding finished depth maps (kf->semidense_flag_). */
+int sdm_mark_depth_present(sdm_ctx *ctx, int n, const int *slots);
+
+/* ---- multi-GPU exchange: the path's one collective step -------------------------- */
+/* Keyframes shard in contiguous blocks, one process per GPU.  K1-K3 need no communication; K4
+ * (InterKeyFrameDepthChecking, PM.cc:628-799) reads the neighbours' FINISHED {rho,sigma} maps, which
+ * cross GPUs once per pass -- over RCCL (xGMI inside a node).  The reference is single-process and has
+ * nothing to replace here; SURVEY.md §8(b) sketches this entry as `sdm_allgather`.
+ * A communicator is built from an RCCL unique id (rank 0 creates it and hands the 128 bytes to the other
+ * ranks through any channel it likes -- a file, MPI, torch.distributed) or borrowed from the caller.
+ * With world == 1 every exchange call is a no-op that returns SDM_OK and RCCL is never loaded. */
+#define SDM_COMM_ID_BYTES 128
+int sdm_comm_unique_id(unsigned char id[SDM_COMM_ID_BYTES]);                 /* ncclGetUniqueId  */
+int sdm_comm_init(sdm_ctx *ctx, const unsigned char id[SDM_COMM_ID_BYTES], int world, int rank);
+int sdm_comm_attach(sdm_ctx *ctx, void *nccl_comm); /* borrow an existing ncclComm_t (not destroyed) */
+int sdm_comm_destroy(sdm_ctx *ctx);
+int sdm_comm_info(sdm_ctx *ctx, int *world, int *rank);
+/* Halo form: send the maps in send_slot[i] to rank send_peer[i], receive rank recv_peer[i]'s maps into
+ * recv_slot[i]; per peer pair the k-th send matches the k-th receive.  _begin returns at once: the
+ * transfers run on a second stream behind everything queued so far, and work queued afterwards (the
+ * interior keyframes' sdm_recon) overlaps them; sdm_exchange_wait orders later work (sdm_inter_check)
+ * behind the transfers.  Neither call waits on the host. */
+int sdm_exchange_halo_begin(sdm_ctx *ctx, int n_send, const int *send_peer, const int *send_slot,
+                            int n_recv, const int *recv_peer, const int *recv_slot);
+int sdm_exchange_wait(sdm_ctx *ctx);
+int sdm_exchange_halo(sdm_ctx *ctx, int n_send, const int *send_peer, const int *send_slot,
+                      int n_recv, const int *recv_peer, const int *recv_slot); /* begin + wait */
+/* All-gather form (BASELINE.json's wording): every rank contributes `count` maps from local slot
+ * first_slot on.  n_fetch < 0: in place, the pool holds world*count slots with slot == global
+ * keyframe index and first_slot == rank*count.  n_fetch >= 0: gathered into an engine-owned buffer;
+ * map number fetch_index[i] (= owner_rank*count + position in the owner's block) is copied into local
+ * slot dst_slot[i].  Stream-ordered; no host wait. */
+int sdm_allgather_depth(sdm_ctx *ctx, int first_slot, int count, int n_fetch, const int *fetch_index,
+                        const int *dst_slot);
 
 /* ---- stand-alone map operations with the reference's signatures -------------------------------- */
 /* IntraKeyFrameDepthChecking(cv::Mat&, cv::Mat&, const cv::Mat) PM.h:85; host maps, in place. */

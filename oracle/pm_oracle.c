@@ -496,6 +496,36 @@ void pmo_fuse(const pmo_hypo *h, int n, const pmo_params *prm, pmo_hypo *dist)
 }
 
 /* ---- PM.cc:197-231 hot loop 1 ---- */
+/* one image row of the loop (the unit the reference's `#pragma omp parallel for ... collapse(2)` at
+ * PM.cc:197 would hand out) */
+static void search_fuse_row(const pmo_keyframe *ref, const pmo_keyframe *nbrs, const pmo_pair *pairs,
+                            const float *rot, int n, float min_depth, float max_depth,
+                            const pmo_params *prm, int y, float *rho, float *sigma, pmo_stats *st)
+{
+    const int W = ref->W;
+    for (int x = 2; x < W - 2; x++) {
+        if (ref->grad[y * W + x] < prm->lambdaG) continue; /* PM.cc:201 */
+        pmo_hypo ho[PMO_MAX_NBR];
+        int nh = 0;
+        for (int j = 0; j < n; j++) {
+            pmo_hypo dh;
+            pmo_epipolar_search(ref, &nbrs[j], &pairs[j], x, y, min_depth, max_depth, rot ? rot[j] : 0.0f,
+                                prm, &dh, 0, 0, st);
+            if (dh.supported && (double)(1 / dh.rho) > 0.0) ho[nh++] = dh; /* PM.cc:216 */
+        }
+        st->hypotheses += nh;
+        if (nh > prm->lambdaN) { /* PM.cc:221 */
+            pmo_hypo f;
+            pmo_fuse(ho, nh, prm, &f);
+            if (f.supported) {
+                rho[y * W + x] = f.rho;
+                sigma[y * W + x] = f.sigma;
+                st->fused++;
+            }
+        }
+    }
+}
+
 void pmo_recon_search_fuse(const pmo_keyframe *ref, const pmo_keyframe *nbrs, const float *rot,
                            int n, float min_depth, float max_depth, const pmo_params *prm,
                            float *rho, float *sigma, pmo_stats *st)
@@ -512,31 +542,13 @@ void pmo_recon_search_fuse(const pmo_keyframe *ref, const pmo_keyframe *nbrs, co
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : s_search, s_cand, s_gate, s_hyp, s_fused)
 #endif
     for (int y = 2; y < H - 2; y++) {
-        for (int x = 2; x < W - 2; x++) {
-            if (ref->grad[y * W + x] < prm->lambdaG) continue; /* PM.cc:201 */
-            pmo_hypo ho[PMO_MAX_NBR];
-            int nh = 0;
-            pmo_stats ls = {0, 0, 0, 0, 0};
-            for (int j = 0; j < n; j++) {
-                pmo_hypo dh;
-                pmo_epipolar_search(ref, &nbrs[j], &pairs[j], x, y, min_depth, max_depth, rot[j],
-                                    prm, &dh, 0, 0, &ls);
-                if (dh.supported && (double)(1 / dh.rho) > 0.0) ho[nh++] = dh; /* PM.cc:216 */
-            }
-            s_search += ls.searches;
-            s_cand += ls.candidates;
-            s_gate += ls.gate_pass;
-            s_hyp += nh;
-            if (nh > prm->lambdaN) { /* PM.cc:221 */
-                pmo_hypo f;
-                pmo_fuse(ho, nh, prm, &f);
-                if (f.supported) {
-                    rho[y * W + x] = f.rho;
-                    sigma[y * W + x] = f.sigma;
-                    s_fused++;
-                }
-            }
-        }
+        pmo_stats ls = {0, 0, 0, 0, 0};
+        search_fuse_row(ref, nbrs, pairs, rot, n, min_depth, max_depth, prm, y, rho, sigma, &ls);
+        s_search += ls.searches;
+        s_cand += ls.candidates;
+        s_gate += ls.gate_pass;
+        s_hyp += ls.hypotheses;
+        s_fused += ls.fused;
     }
     if (st) {
         st->searches += s_search;
@@ -652,77 +664,84 @@ void pmo_semi_dense_recon(const pmo_keyframe *ref, const pmo_keyframe *nbrs, con
 }
 
 /* ---- PM.cc:628-799 ---- */
+/* one image row of the loop at PM.cc:659-660 */
+static void inter_check_row(const pmo_keyframe *cur, float *cur_rho, const pmo_keyframe *nbrs,
+                            const pmo_pair *pairs, const float *const *nbr_rho,
+                            const float *const *nbr_sigma, int n, const pmo_params *prm, int py)
+{
+    const int cols = cur->W, rows = cur->H;
+    const float fx = cur->fx, fy = cur->fy, cx = cur->cx, cy = cur->cy;
+    for (int px = 2; px < cols - 2; px++) {
+        float depthp = cur_rho[py * cols + px];
+        if ((double)depthp < 0.000001) continue; /* PM.cc:662 */
+        int kf_count = 0;
+        /* Gauss-Newton sums over compatible (j,n) in order, PM.cc:771-791 */
+        float sum_Jr = 0.f, sum_JJ = 0.f;
+        float xp0 = ((float)px - cx) / fx, xp1 = ((float)py - cy) / fy; /* PM.cc:677 */
+        float dp = 1 / depthp;                                          /* PM.cc:769 */
+        for (int j = 0; j < n; j++) {
+            const pmo_keyframe *kj = &nbrs[j];
+            const float *R = pairs[j].R21, *t = pairs[j].t21;
+            /* temp = Rji*xp/depthp + tji ; Xj = K*temp ; Xj /= Xj(2)   PM.cc:678-680 */
+            float t0 = row_dot_xp(R + 0, xp0, xp1) / depthp + t[0];
+            float t1 = row_dot_xp(R + 3, xp0, xp1) / depthp + t[1];
+            float rzxp = row_dot_xp(R + 6, xp0, xp1);
+            float t2 = rzxp / depthp + t[2];
+            float u = kj->fx * t0 + kj->cx * t2; /* N8 */
+            float v = kj->fy * t1 + kj->cy * t2;
+            float xj = u / t2, yj = v / t2;
+            /* Eq.12  PM.cc:684-688 */
+            float denom2 = depthp * t[2];
+            float depthj = depthp / (rzxp + denom2);
+            if (!(xj >= 0 && xj < (float)(cols - 1) && yj >= 0 && yj < (float)(rows - 1)))
+                continue; /* PM.cc:695 + N8 */
+            int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
+            int x1 = x0 + 1, y1 = y0 + 1;
+            const int tx[4] = {x0, x0, x1, x1}; /* order PM.cc:705,717,729,741 */
+            const int ty[4] = {y0, y1, y0, y1};
+            int nj = 0;
+            for (int k = 0; k < 4; k++) {
+                float d = nbr_rho[j][ty[k] * kj->W + tx[k]];
+                float sg = nbr_sigma[j][ty[k] * kj->W + tx[k]];
+                if ((double)d > 0.000001) {
+                    float dd = depthj - d;
+                    float test = (float)(((double)dd * (double)dd) / ((double)sg * (double)sg));
+                    if ((double)test < 3.84) {
+                        nj++;
+                        /* PM.cc:777-783 */
+                        float djn = 1 / d;
+                        float d2sigma = djn * djn * sg;
+                        float J = -rzxp / d2sigma;
+                        float r0 = (djn - dp * rzxp - t[2]) / d2sigma;
+                        sum_Jr = sum_Jr + J * r0;
+                        sum_JJ = sum_JJ + J * J;
+                    }
+                }
+            }
+            if (nj >= 1) kf_count++;
+        }
+        if (kf_count < prm->lambdaN) {
+            cur_rho[py * cols + px] = 0.0f; /* PM.cc:764: sigma untouched */
+        } else {
+            float dpDelta = (-sum_Jr) / sum_JJ;       /* PM.cc:788-791 */
+            cur_rho[py * cols + px] = 1 / (dp + dpDelta); /* PM.cc:793 */
+        }
+    }
+}
+
 void pmo_inter_check(const pmo_keyframe *cur, float *cur_rho, const pmo_keyframe *nbrs,
                      const float *const *nbr_rho, const float *const *nbr_sigma, int n,
                      const pmo_params *prm)
 {
     if (n > PMO_MAX_NBR) n = PMO_MAX_NBR;
-    const int cols = cur->W, rows = cur->H;
-    const float fx = cur->fx, fy = cur->fy, cx = cur->cx, cy = cur->cy;
+    const int rows = cur->H;
     pmo_pair *pairs = (pmo_pair *)malloc(sizeof(pmo_pair) * (size_t)(n > 0 ? n : 1));
     for (int j = 0; j < n; j++) pmo_pair_geometry(cur, &nbrs[j], &pairs[j]); /* PM.cc:634-649 */
-
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
-    for (int py = 2; py < rows - 2; py++) {
-        for (int px = 2; px < cols - 2; px++) {
-            float depthp = cur_rho[py * cols + px];
-            if ((double)depthp < 0.000001) continue; /* PM.cc:662 */
-            int kf_count = 0;
-            /* Gauss-Newton sums over compatible (j,n) in order, PM.cc:771-791 */
-            float sum_Jr = 0.f, sum_JJ = 0.f;
-            float xp0 = ((float)px - cx) / fx, xp1 = ((float)py - cy) / fy; /* PM.cc:677 */
-            float dp = 1 / depthp;                                          /* PM.cc:769 */
-            for (int j = 0; j < n; j++) {
-                const pmo_keyframe *kj = &nbrs[j];
-                const float *R = pairs[j].R21, *t = pairs[j].t21;
-                /* temp = Rji*xp/depthp + tji ; Xj = K*temp ; Xj /= Xj(2)   PM.cc:678-680 */
-                float t0 = row_dot_xp(R + 0, xp0, xp1) / depthp + t[0];
-                float t1 = row_dot_xp(R + 3, xp0, xp1) / depthp + t[1];
-                float rzxp = row_dot_xp(R + 6, xp0, xp1);
-                float t2 = rzxp / depthp + t[2];
-                float u = kj->fx * t0 + kj->cx * t2; /* N8 */
-                float v = kj->fy * t1 + kj->cy * t2;
-                float xj = u / t2, yj = v / t2;
-                /* Eq.12  PM.cc:684-688 */
-                float denom2 = depthp * t[2];
-                float depthj = depthp / (rzxp + denom2);
-                if (!(xj >= 0 && xj < (float)(cols - 1) && yj >= 0 && yj < (float)(rows - 1)))
-                    continue; /* PM.cc:695 + N8 */
-                int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
-                int x1 = x0 + 1, y1 = y0 + 1;
-                const int tx[4] = {x0, x0, x1, x1}; /* order PM.cc:705,717,729,741 */
-                const int ty[4] = {y0, y1, y0, y1};
-                int nj = 0;
-                for (int k = 0; k < 4; k++) {
-                    float d = nbr_rho[j][ty[k] * kj->W + tx[k]];
-                    float sg = nbr_sigma[j][ty[k] * kj->W + tx[k]];
-                    if ((double)d > 0.000001) {
-                        float dd = depthj - d;
-                        float test = (float)(((double)dd * (double)dd) / ((double)sg * (double)sg));
-                        if ((double)test < 3.84) {
-                            nj++;
-                            /* PM.cc:777-783 */
-                            float djn = 1 / d;
-                            float d2sigma = djn * djn * sg;
-                            float J = -rzxp / d2sigma;
-                            float r0 = (djn - dp * rzxp - t[2]) / d2sigma;
-                            sum_Jr = sum_Jr + J * r0;
-                            sum_JJ = sum_JJ + J * J;
-                        }
-                    }
-                }
-                if (nj >= 1) kf_count++;
-            }
-            if (kf_count < prm->lambdaN) {
-                cur_rho[py * cols + px] = 0.0f; /* PM.cc:764: sigma untouched */
-            } else {
-                float dpDelta = (-sum_Jr) / sum_JJ;       /* PM.cc:788-791 */
-                cur_rho[py * cols + px] = 1 / (dp + dpDelta); /* PM.cc:793 */
-            }
-        }
-    }
+    for (int py = 2; py < rows - 2; py++)
+        inter_check_row(cur, cur_rho, nbrs, pairs, nbr_rho, nbr_sigma, n, prm, py);
     free(pairs);
 }
 
@@ -755,4 +774,104 @@ void pmo_pointset(const pmo_keyframe *kf, const float *rho, float *xyz)
                 o[i] = ((Rwc[i * 3 + 0] * X + Rwc[i * 3 + 1] * Y) + Rwc[i * 3 + 2] * Z) + Ow[i] * 1.0f;
         }
     }
+}
+
+/* ---- keyframe-batched drivers for the TIMED CPU baseline (bench.py cpu_baseline) -----------------
+ * The reference's driver visits keyframes one after another (PM.cc:262-315) with its OpenMP pragmas
+ * over image rows (PM.cc:197,491,554,658) -- which are inert in its build.  These two entry points run
+ * the same per-keyframe functions as above over a whole batch, with the rows of ALL keyframes handed
+ * out to the threads at once (collapse over (keyframe,row)), so that many cores stay busy and no
+ * per-keyframe call goes through Python.  Results are identical to calling the per-keyframe
+ * functions in a loop (the units are independent: snapshot semantics). */
+void pmo_recon_batch(const pmo_keyframe *kfs, const int *ref_idx, int n_ref, const int *nbr_idx, int n,
+                     float min_depth, float max_depth, const pmo_params *prm, float *rho,
+                     float *sigma, pmo_stats *st)
+{
+    if (n_ref <= 0) return;
+    if (n > PMO_MAX_NBR) n = PMO_MAX_NBR;
+    const int W = kfs[ref_idx[0]].W, H = kfs[ref_idx[0]].H;
+    const size_t P = (size_t)W * H;
+    pmo_pair *pairs = (pmo_pair *)malloc(sizeof(pmo_pair) * (size_t)n_ref * (size_t)(n > 0 ? n : 1));
+    pmo_keyframe *nb = (pmo_keyframe *)malloc(sizeof(pmo_keyframe) * (size_t)n_ref * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n_ref; i++)
+        for (int j = 0; j < n; j++) {
+            nb[(size_t)i * n + j] = kfs[nbr_idx[(size_t)i * n + j]];
+            pmo_pair_geometry(&kfs[ref_idx[i]], &nb[(size_t)i * n + j], &pairs[(size_t)i * n + j]);
+        }
+    memset(rho, 0, sizeof(float) * P * (size_t)n_ref);
+    memset(sigma, 0, sizeof(float) * P * (size_t)n_ref);
+    long long s_search = 0, s_cand = 0, s_gate = 0, s_hyp = 0, s_fused = 0;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 4) reduction(+ : s_search, s_cand, s_gate, s_hyp, s_fused)
+#endif
+    for (int i = 0; i < n_ref; i++)
+        for (int y = 2; y < H - 2; y++) {
+            pmo_stats ls = {0, 0, 0, 0, 0};
+            search_fuse_row(&kfs[ref_idx[i]], nb + (size_t)i * n, pairs + (size_t)i * n, 0, n, min_depth,
+                            max_depth, prm, y, rho + P * i, sigma + P * i, &ls);
+            s_search += ls.searches;
+            s_cand += ls.candidates;
+            s_gate += ls.gate_pass;
+            s_hyp += ls.hypotheses;
+            s_fused += ls.fused;
+        }
+    /* PM.cc:237-238 per keyframe (the row loops inside run on one thread each: nested teams are off) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int i = 0; i < n_ref; i++) {
+        pmo_intra_check(rho + P * i, sigma + P * i, W, H);
+        pmo_intra_grow(rho + P * i, sigma + P * i, kfs[ref_idx[i]].grad, W, H, prm);
+    }
+    if (st) {
+        st->searches += s_search;
+        st->candidates += s_cand;
+        st->gate_pass += s_gate;
+        st->hypotheses += s_hyp;
+        st->fused += s_fused;
+    }
+    free(pairs);
+    free(nb);
+}
+
+/* PM.cc:300-306 for a batch: chk[i] = rho_in[i] checked against the neighbours' maps (map_rho /
+ * map_sigma are indexed like kfs), then the point set of the checked map (xyz may be NULL). */
+void pmo_inter_pointset_batch(const pmo_keyframe *kfs, const int *ref_idx, int n_ref, const int *nbr_idx,
+                              int n, const float *const *map_rho, const float *const *map_sigma,
+                              const pmo_params *prm, const float *rho_in, float *chk, float *xyz)
+{
+    if (n_ref <= 0) return;
+    if (n > PMO_MAX_NBR) n = PMO_MAX_NBR;
+    const int W = kfs[ref_idx[0]].W, H = kfs[ref_idx[0]].H;
+    const size_t P = (size_t)W * H, nn = (size_t)(n > 0 ? n : 1);
+    pmo_pair *pairs = (pmo_pair *)malloc(sizeof(pmo_pair) * (size_t)n_ref * nn);
+    pmo_keyframe *nb = (pmo_keyframe *)malloc(sizeof(pmo_keyframe) * (size_t)n_ref * nn);
+    const float **nr = (const float **)malloc(sizeof(float *) * (size_t)n_ref * nn);
+    const float **ns = (const float **)malloc(sizeof(float *) * (size_t)n_ref * nn);
+    for (int i = 0; i < n_ref; i++)
+        for (int j = 0; j < n; j++) {
+            const int k = nbr_idx[(size_t)i * n + j];
+            nb[(size_t)i * n + j] = kfs[k];
+            nr[(size_t)i * n + j] = map_rho[k];
+            ns[(size_t)i * n + j] = map_sigma[k];
+            pmo_pair_geometry(&kfs[ref_idx[i]], &kfs[k], &pairs[(size_t)i * n + j]);
+        }
+    memcpy(chk, rho_in, sizeof(float) * P * (size_t)n_ref);
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+#endif
+    for (int i = 0; i < n_ref; i++)
+        for (int py = 2; py < H - 2; py++)
+            inter_check_row(&kfs[ref_idx[i]], chk + P * i, nb + (size_t)i * n, pairs + (size_t)i * n,
+                            nr + (size_t)i * n, ns + (size_t)i * n, n, prm, py);
+    if (xyz) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+        for (int i = 0; i < n_ref; i++) pmo_pointset(&kfs[ref_idx[i]], chk + P * i, xyz + 3 * P * i);
+    }
+    free(pairs);
+    free(nb);
+    free(nr);
+    free(ns);
 }

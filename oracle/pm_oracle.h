@@ -127,6 +127,17 @@ void pmo_inter_check(const pmo_keyframe *cur, float *cur_rho, const pmo_keyframe
 /* PM.cc:337-367: xyz is H x 3W; only the 2-px-inset domain is written. */
 void pmo_pointset(const pmo_keyframe *kf, const float *rho, float *xyz);
 
+/* Keyframe-batched drivers for the timed CPU baseline: rows of all keyframes are shared out to the
+ * OpenMP threads at once.  kfs is indexed by the entries of ref_idx / nbr_idx ([n_ref] / [n_ref][n]);
+ * rho, sigma, rho_in, chk are [n_ref][H*W], xyz [n_ref][3*H*W] or NULL; map_rho/map_sigma are
+ * indexed like kfs (the neighbours' finished maps, snapshot semantics). */
+void pmo_recon_batch(const pmo_keyframe *kfs, const int *ref_idx, int n_ref, const int *nbr_idx, int n,
+                     float min_depth, float max_depth, const pmo_params *prm, float *rho,
+                     float *sigma, pmo_stats *st);
+void pmo_inter_pointset_batch(const pmo_keyframe *kfs, const int *ref_idx, int n_ref, const int *nbr_idx,
+                              int n, const float *const *map_rho, const float *const *map_sigma,
+                              const pmo_params *prm, const float *rho_in, float *chk, float *xyz);
+
 /* number of OpenMP threads the oracle was built for / will use (1 if built without -fopenmp) */
 int pmo_num_threads(void);
 

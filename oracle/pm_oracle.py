@@ -95,6 +95,12 @@ class Oracle:
                                       C.POINTER(f32p), C.POINTER(f32p), C.c_int, C.POINTER(ParamsC)]
         L.pmo_pointset.argtypes = [C.POINTER(KeyFrameC), f32p, f32p]
         L.pmo_num_threads.restype = C.c_int
+        ip = C.POINTER(C.c_int)
+        L.pmo_recon_batch.argtypes = [C.POINTER(KeyFrameC), ip, C.c_int, ip, C.c_int, C.c_float, C.c_float,
+                                      C.POINTER(ParamsC), f32p, f32p, C.POINTER(StatsC)]
+        L.pmo_inter_pointset_batch.argtypes = [C.POINTER(KeyFrameC), ip, C.c_int, ip, C.c_int,
+                                               C.POINTER(f32p), C.POINTER(f32p), C.POINTER(ParamsC),
+                                               f32p, f32p, f32p]
         self.params = ParamsC()
         L.pmo_default_params(C.byref(self.params))
 
@@ -250,3 +256,47 @@ class Oracle:
         xyz = np.zeros((kf.H, 3 * kf.W), np.float32)
         self.lib.pmo_pointset(C.byref(kf), rp, xyz.ctypes.data_as(C.POINTER(C.c_float)))
         return xyz
+
+    # -- keyframe-batched drivers (timed CPU baseline; rows of all keyframes shared out to the threads) --
+    def recon_batch(self, kfs, ref_idx, nbr_idx, min_depth, max_depth):
+        """kfs: list of KeyFrameC; ref_idx [n_ref], nbr_idx [n_ref][n] index into it.
+        Returns rho, sigma [n_ref,H,W] and the scan statistics."""
+        arr = self.kf_array(kfs)
+        ri = np.ascontiguousarray(ref_idx, dtype=np.int32)
+        ni = np.ascontiguousarray(nbr_idx, dtype=np.int32).reshape(len(ri), -1)
+        H, W = kfs[0].H, kfs[0].W
+        rho = np.empty((len(ri), H, W), np.float32)
+        sigma = np.empty((len(ri), H, W), np.float32)
+        st = StatsC()
+        ip, f32p = C.POINTER(C.c_int), C.POINTER(C.c_float)
+        self.lib.pmo_recon_batch(arr, ri.ctypes.data_as(ip), len(ri), ni.ctypes.data_as(ip), ni.shape[1],
+                                 min_depth, max_depth, C.byref(self.params), rho.ctypes.data_as(f32p),
+                                 sigma.ctypes.data_as(f32p), C.byref(st))
+        return rho, sigma, {k: int(getattr(st, k)) for k, _ in StatsC._fields_}
+
+    def inter_pointset_batch(self, kfs, ref_idx, nbr_idx, map_rho, map_sigma, rho_in, with_xyz=True):
+        """map_rho/map_sigma: per entry of kfs, the finished map (None where no reference reads it)."""
+        arr = self.kf_array(kfs)
+        ri = np.ascontiguousarray(ref_idx, dtype=np.int32)
+        ni = np.ascontiguousarray(nbr_idx, dtype=np.int32).reshape(len(ri), -1)
+        H, W = kfs[0].H, kfs[0].W
+        ip, f32p = C.POINTER(C.c_int), C.POINTER(C.c_float)
+        keep = []
+
+        def ptrs(maps):
+            out = (f32p * len(kfs))()
+            for i, m in enumerate(maps):
+                if m is not None:
+                    a = np.ascontiguousarray(m, dtype=np.float32)
+                    keep.append(a)
+                    out[i] = a.ctypes.data_as(f32p)
+            return out
+        rp, sp = ptrs(map_rho), ptrs(map_sigma)
+        rin = np.ascontiguousarray(rho_in, dtype=np.float32)
+        chk = np.empty((len(ri), H, W), np.float32)
+        xyz = np.zeros((len(ri), H, 3 * W), np.float32) if with_xyz else None
+        self.lib.pmo_inter_pointset_batch(arr, ri.ctypes.data_as(ip), len(ri), ni.ctypes.data_as(ip), ni.shape[1],
+                                          rp, sp, C.byref(self.params), rin.ctypes.data_as(f32p),
+                                          chk.ctypes.data_as(f32p),
+                                          xyz.ctypes.data_as(f32p) if with_xyz else None)
+        return chk, xyz

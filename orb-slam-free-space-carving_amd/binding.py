@@ -71,6 +71,16 @@ SYMBOLS = [
     ("sdm_download_pointset", C.c_int, [_ctx, C.c_int, _f32p]),
     ("sdm_depth_pool_ptr", C.c_void_p, [_ctx]),
     ("sdm_assume_pipeline_maps", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_mark_depth_present", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
+    ("sdm_comm_init", C.c_int, [_ctx, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
+    ("sdm_comm_attach", C.c_int, [_ctx, C.c_void_p]),
+    ("sdm_comm_destroy", C.c_int, [_ctx]),
+    ("sdm_comm_info", C.c_int, [_ctx, _ip, _ip]),
+    ("sdm_exchange_halo_begin", C.c_int, [_ctx, C.c_int, _ip, _ip, C.c_int, _ip, _ip]),
+    ("sdm_exchange_wait", C.c_int, [_ctx]),
+    ("sdm_exchange_halo", C.c_int, [_ctx, C.c_int, _ip, _ip, C.c_int, _ip, _ip]),
+    ("sdm_allgather_depth", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_intra_grow_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_epipolar_search", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -300,6 +310,56 @@ class Engine:
         x = np.empty((self.H, 3 * self.W), np.float32)
         self._check(self.lib.sdm_download_pointset(self.ctx, slot, x.ctypes.data_as(_f32p)))
         return x
+
+    def mark_depth_present(self, slots):
+        r, rp = _i32(np.asarray(slots).reshape(-1))
+        self._check(self.lib.sdm_mark_depth_present(self.ctx, len(r), rp))
+
+    # -- multi-GPU exchange (RCCL inside the engine) -----------------------------------------------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * self.COMM_ID_BYTES)()
+        self._check(self.lib.sdm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, uid, world, rank):
+        buf = (C.c_ubyte * self.COMM_ID_BYTES).from_buffer_copy(uid) if uid is not None else None
+        self._check(self.lib.sdm_comm_init(self.ctx, buf, world, rank))
+
+    def comm_destroy(self):
+        self._check(self.lib.sdm_comm_destroy(self.ctx))
+
+    def comm_info(self):
+        w, r = C.c_int(), C.c_int()
+        self._check(self.lib.sdm_comm_info(self.ctx, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
+
+    def _xchg_args(self, send, recv):
+        sp, ss = _i32([p for p, _ in send]), _i32([s for _, s in send])
+        rp, rs = _i32([p for p, _ in recv]), _i32([s for _, s in recv])
+        return (len(send), sp[1], ss[1], len(recv), rp[1], rs[1]), (sp, ss, rp, rs)
+
+    def exchange_halo_begin(self, send, recv):
+        """send / recv: lists of (peer_rank, local_slot)"""
+        args, keep = self._xchg_args(send, recv)
+        self._check(self.lib.sdm_exchange_halo_begin(self.ctx, *args))
+
+    def exchange_wait(self):
+        self._check(self.lib.sdm_exchange_wait(self.ctx))
+
+    def exchange_halo(self, send, recv):
+        args, keep = self._xchg_args(send, recv)
+        self._check(self.lib.sdm_exchange_halo(self.ctx, *args))
+
+    def allgather_depth(self, first_slot, count, fetch=None):
+        """fetch: None = in place (slot == global keyframe index), else list of (gathered_index, local_slot)"""
+        if fetch is None:
+            self._check(self.lib.sdm_allgather_depth(self.ctx, first_slot, count, -1, None, None))
+            return
+        fi, fip = _i32([i for i, _ in fetch])
+        ds, dsp = _i32([s for _, s in fetch])
+        self._check(self.lib.sdm_allgather_depth(self.ctx, first_slot, count, len(fetch), fip, dsp))
 
     def assume_pipeline_maps(self, slots):
         r, rp = _i32(np.asarray(slots).reshape(-1))

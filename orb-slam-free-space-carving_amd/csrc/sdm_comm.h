@@ -1,0 +1,315 @@
+// sdm_comm.h -- the path's ONE exchange step between GPUs, native in the C ABI.
+//
+// InterKeyFrameDepthChecking of keyframe k (PM.cc:628-799) reads the FINISHED {rho,sigma} maps of k's
+// covisible neighbours (the reference gates on that at PM.cc:292-298).  With keyframes sharded in
+// contiguous blocks over the GPUs of a node, those maps cross GPUs once per pass, between K3 and K4:
+//   halo       point-to-point ncclSend/ncclRecv of exactly the maps a peer's K4 reads (xGMI is
+//              point-to-point: 2 x (N/2) x 8P bytes per rank over two direct links, independent of world
+//              size), issued on a second stream behind an event so it overlaps the interior keyframes' K1-K3;
+//   all-gather ncclAllGather of every rank's block (BASELINE.json's wording), in place in the depth pool when
+//              slot == global keyframe index, or into an engine-owned buffer from which the needed maps are
+//              copied to local slots.
+// RCCL is resolved with dlopen at the first sdm_comm_* call: a single-GPU user never loads it, and inside a
+// process that already holds torch's librccl.so.1 the same library instance is used.
+// Included by sdm_engine.hip after sdm_ctx is defined (one translation unit).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return SDM_OK;
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(SDM_ECOMM, std::string("cannot load RCCL (librccl.so.1): ") + dlerror());
+    RcclApi a;
+    a.handle = h;
+#define SDM_RCCL_SYM(field, name)                                                         \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                        \
+    if (!a.field) return fail(SDM_ECOMM, std::string("RCCL symbol missing: ") + name)
+    SDM_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    SDM_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    SDM_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    SDM_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    SDM_RCCL_SYM(GroupStart, "ncclGroupStart");
+    SDM_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    SDM_RCCL_SYM(Send, "ncclSend");
+    SDM_RCCL_SYM(Recv, "ncclRecv");
+    SDM_RCCL_SYM(AllGather, "ncclAllGather");
+    SDM_RCCL_SYM(CommCount, "ncclCommCount");
+    SDM_RCCL_SYM(CommUserRank, "ncclCommUserRank");
+#undef SDM_RCCL_SYM
+    g_rccl = a;
+    return SDM_OK;
+}
+
+#define RCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r__ = (expr);                                                              \
+        if (r__ != ncclSuccess)                                                                 \
+            return fail(SDM_ECOMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r__));     \
+    } while (0)
+
+// second stream + the two events that order it against the compute stream
+int comm_streams(sdm_ctx* c)
+{
+    if (c->comm_stream) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_maps_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_xchg_done, hipEventDisableTiming));
+    return SDM_OK;
+}
+
+void comm_release(sdm_ctx* c)
+{
+    if (c->comm && c->own_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    c->own_comm = false;
+    c->world = 1;
+    c->rank = 0;
+    if (c->comm_stream) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipStreamDestroy(c->comm_stream);
+        c->comm_stream = nullptr;
+    }
+    if (c->ev_maps_ready) (void)hipEventDestroy(c->ev_maps_ready);
+    if (c->ev_xchg_done) (void)hipEventDestroy(c->ev_xchg_done);
+    c->ev_maps_ready = c->ev_xchg_done = nullptr;
+    (void)hipFree(c->gather_buf);
+    c->gather_buf = nullptr;
+    c->gather_slots = 0;
+    c->xchg_pending = false;
+}
+
+int check_xchg_slots(sdm_ctx* c, int n, const int* peer, const int* slot, const char* what)
+{
+    if (n < 0 || (n > 0 && (!peer || !slot))) return fail(SDM_EINVAL, std::string("bad ") + what + " list");
+    for (int i = 0; i < n; i++) {
+        if (slot[i] < 0 || slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, std::string(what) + " slot out of range");
+        if (peer[i] < 0 || peer[i] >= c->world || peer[i] == c->rank)
+            return fail(SDM_EINVAL, std::string(what) + " peer out of range (or self)");
+    }
+    return SDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdm_comm_unique_id(unsigned char id[SDM_COMM_ID_BYTES])
+{
+    static_assert(SDM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    if (!id) return fail(SDM_EINVAL, "null id");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId u;
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, SDM_COMM_ID_BYTES);
+    return SDM_OK;
+}
+
+int sdm_comm_init(sdm_ctx* c, const unsigned char id[SDM_COMM_ID_BYTES], int world, int rank)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SDM_EINVAL, "bad world/rank");
+    if (c->comm || c->world != 1) return fail(SDM_ESTATE, "context already has a communicator");
+    if (world == 1) return SDM_OK;  // nothing to exchange: every sdm_exchange_* call is a no-op
+    if (!id) return fail(SDM_EINVAL, "null id");
+    int rc = load_rccl();
+    if (rc) return rc;
+    if ((rc = comm_streams(c))) return rc;
+    ncclUniqueId u;
+    memcpy(u.internal, id, SDM_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, u, rank));
+    c->comm = comm;
+    c->own_comm = true;
+    c->world = world;
+    c->rank = rank;
+    return SDM_OK;
+}
+
+int sdm_comm_attach(sdm_ctx* c, void* nccl_comm)
+{
+    if (!c || !nccl_comm) return fail(SDM_EINVAL, "null argument");
+    if (c->comm || c->world != 1) return fail(SDM_ESTATE, "context already has a communicator");
+    int rc = load_rccl();
+    if (rc) return rc;
+    int world = 0, rank = 0;
+    RCCL_TRY(g_rccl.CommCount((ncclComm_t)nccl_comm, &world));
+    RCCL_TRY(g_rccl.CommUserRank((ncclComm_t)nccl_comm, &rank));
+    if (world > 1 && (rc = comm_streams(c))) return rc;
+    c->comm = nccl_comm;
+    c->own_comm = false;
+    c->world = world;
+    c->rank = rank;
+    return SDM_OK;
+}
+
+int sdm_comm_destroy(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    comm_release(c);
+    return SDM_OK;
+}
+
+int sdm_comm_info(sdm_ctx* c, int* world, int* rank)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    return SDM_OK;
+}
+
+// Starts the halo exchange: everything queued on the context's stream so far (the boundary keyframes'
+// K1-K3) is finished before the maps leave; the transfers run on the exchange stream, so work queued
+// on the context's stream after this call (the interior keyframes) overlaps them.
+int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const int* send_slot, int n_recv,
+                            const int* recv_peer, const int* recv_slot)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (c->xchg_pending) return fail(SDM_ESTATE, "an exchange is already in flight: call sdm_exchange_wait first");
+    if (c->world == 1) {
+        if (n_send || n_recv) return fail(SDM_EINVAL, "world size 1 has no peers");
+        return SDM_OK;
+    }
+    int rc;
+    if ((rc = check_xchg_slots(c, n_send, send_peer, send_slot, "send"))) return rc;
+    if ((rc = check_xchg_slots(c, n_recv, recv_peer, recv_slot, "recv"))) return rc;
+    for (int i = 0; i < n_send; i++)
+        if (!c->has_depth[send_slot[i]]) return fail(SDM_ESTATE, "send slot has no reconstructed depth map");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
+    const size_t count = (size_t)c->P * 2;  // floats per map {rho,sigma}
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    // one group: all sends and receives of this rank progress together (no ordering deadlock between peers)
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n_send; i++)
+        RCCL_TRY(g_rccl.Send(c->pool + (long long)send_slot[i] * c->P, count, ncclFloat, send_peer[i], comm,
+                             c->comm_stream));
+    for (int i = 0; i < n_recv; i++)
+        RCCL_TRY(g_rccl.Recv(c->pool + (long long)recv_slot[i] * c->P, count, ncclFloat, recv_peer[i], comm,
+                             c->comm_stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
+    for (int i = 0; i < n_recv; i++) {
+        c->has_depth[recv_slot[i]] = 1;                    // a peer's finished map (semidense_flag_, PM.cc:294)
+        c->recon_lambdaG[recv_slot[i]] = std::nanf("");    // this rank did not reconstruct it
+    }
+    c->xchg_pending = true;
+    return SDM_OK;
+}
+
+// Work queued on the context's stream after this call (K4) sees the received maps.  No host wait.
+int sdm_exchange_wait(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (!c->xchg_pending) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
+    c->xchg_pending = false;
+    return SDM_OK;
+}
+
+int sdm_exchange_halo(sdm_ctx* c, int n_send, const int* send_peer, const int* send_slot, int n_recv,
+                      const int* recv_peer, const int* recv_slot)
+{
+    int rc = sdm_exchange_halo_begin(c, n_send, send_peer, send_slot, n_recv, recv_peer, recv_slot);
+    if (rc) return rc;
+    return sdm_exchange_wait(c);
+}
+
+// All-gather of every rank's block of `count` maps starting at local slot `first_slot`.
+//  n_fetch < 0   in place: the pool holds world*count slots, slot == global keyframe index, and this
+//                rank's block sits at first_slot == rank*count (the SURVEY §8b `sdm_allgather` sketch);
+//  n_fetch >= 0  gathered into an engine-owned buffer [world][count] maps; map fetch_index[i] of that
+//                sequence (= owner_rank*count + position) is then copied into local slot dst_slot[i].
+// Stream-ordered on the context's stream; no host wait.
+int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, const int* fetch_index,
+                        const int* dst_slot)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (count < 1 || first_slot < 0 || first_slot + count > c->cfg.max_keyframes)
+        return fail(SDM_EINVAL, "block out of range");
+    if (n_fetch > 0 && (!fetch_index || !dst_slot)) return fail(SDM_EINVAL, "null fetch list");
+    const long long total = (long long)c->world * count;
+    for (int i = 0; i < n_fetch; i++) {
+        if (fetch_index[i] < 0 || fetch_index[i] >= total) return fail(SDM_EINVAL, "fetch index out of range");
+        if (dst_slot[i] < 0 || dst_slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "fetch slot out of range");
+        if (dst_slot[i] >= first_slot && dst_slot[i] < first_slot + count)
+            return fail(SDM_EINVAL, "fetch would overwrite this rank's own block");
+    }
+    if (n_fetch < 0 && (total > c->cfg.max_keyframes || first_slot != c->rank * count))
+        return fail(SDM_EINVAL, "in-place all-gather needs slot == global keyframe index");
+    for (int r = 0; r < count; r++)
+        if (!c->has_depth[first_slot + r]) return fail(SDM_ESTATE, "block slot has no reconstructed depth map");
+    if (c->world == 1) return SDM_OK;  // this rank's block is all there is
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t block_floats = (size_t)count * (size_t)c->P * 2;
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    if (n_fetch < 0) {
+        RCCL_TRY(g_rccl.AllGather(c->pool + (long long)first_slot * c->P, c->pool, block_floats, ncclFloat, comm,
+                                  c->stream));
+        for (long long s = 0; s < total; s++)
+            if (s < first_slot || s >= first_slot + count) {
+                c->has_depth[s] = 1;
+                c->recon_lambdaG[s] = std::nanf("");
+            }
+        return SDM_OK;
+    }
+    if (c->gather_slots < total) {
+        (void)hipFree(c->gather_buf);
+        c->gather_buf = nullptr;
+        c->gather_slots = 0;
+        HIP_TRY(hipMalloc((void**)&c->gather_buf, sizeof(float2) * (size_t)c->P * (size_t)total));
+        c->gather_slots = total;
+    }
+    RCCL_TRY(g_rccl.AllGather(c->pool + (long long)first_slot * c->P, c->gather_buf, block_floats, ncclFloat, comm,
+                              c->stream));
+    for (int i = 0; i < n_fetch; i++) {
+        HIP_TRY(hipMemcpyAsync(c->pool + (long long)dst_slot[i] * c->P, c->gather_buf + (long long)fetch_index[i] * c->P,
+                               sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+        c->has_depth[dst_slot[i]] = 1;
+        c->recon_lambdaG[dst_slot[i]] = std::nanf("");
+    }
+    return SDM_OK;
+}
+
+// Maps written into the depth pool from outside the engine (an ext_depth_pool filled by the host framework's
+// own collective): marks the slots as holding finished depth maps (kf->semidense_flag_, PM.cc:292-298).
+int sdm_mark_depth_present(sdm_ctx* c, int n, const int* slots)
+{
+    if (!c || (n > 0 && !slots)) return fail(SDM_EINVAL, "null argument");
+    for (int i = 0; i < n; i++) {
+        if (slots[i] < 0 || slots[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "slot out of range");
+        c->has_depth[slots[i]] = 1;
+        c->recon_lambdaG[slots[i]] = std::nanf("");
+    }
+    return SDM_OK;
+}
+
+}  // extern "C"

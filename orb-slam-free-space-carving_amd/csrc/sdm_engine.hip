@@ -131,6 +131,16 @@ struct sdm_ctx {
     bool timing_on = false;
     std::vector<Span> spans;
     size_t spans_used = 0;
+
+    // multi-GPU exchange (sdm_comm.h): RCCL communicator, exchange stream, ordering events
+    void* comm = nullptr;  // ncclComm_t
+    bool own_comm = false;
+    int world = 1, rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_maps_ready = nullptr, ev_xchg_done = nullptr;
+    bool xchg_pending = false;
+    float2* gather_buf = nullptr;  // [world*count] maps, the not-in-place all-gather's landing zone
+    long long gather_slots = 0;
 };
 
 namespace {
@@ -432,6 +442,8 @@ int host_alloc(T** p, size_t count)
 
 }  // namespace
 
+#include "sdm_comm.h"
+
 extern "C" {
 
 void sdm_default_params(sdm_params* p)
@@ -588,6 +600,7 @@ void sdm_destroy(sdm_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     (void)hipFree(c->rec);
     if (c->own_pool) (void)hipFree(c->pool);
     (void)hipFree(c->scratch);
@@ -935,6 +948,20 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (n < 1) return fail(SDM_EINVAL, "need at least one neighbour");
+    if (!ref_slots || !nbr_slots || n_ref < 1) return fail(SDM_EINVAL, "null or empty slot list");
+    // the reference runs the check only when the keyframe and all its neighbours have been reconstructed
+    // (semidense_flag_, PM.cc:292-298): a slot whose map is still the zero map of a fresh upload is a caller error
+    for (int r = 0; r < n_ref; r++) {
+        if (ref_slots[r] < 0 || ref_slots[r] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "slot out of range");
+        if (!c->has_depth[ref_slots[r]]) return fail(SDM_ESTATE, "reference slot has no depth map (run sdm_recon first)");
+        for (int j = 0; j < n; j++) {
+            const int s = nbr_slots[r * n + j];
+            if (s < 0 || s >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "slot out of range");
+            if (!c->has_depth[s])
+                return fail(SDM_ESTATE, "neighbour slot has no depth map (sdm_recon, sdm_upload_depth, an sdm_exchange_* "
+                                        "call or sdm_mark_depth_present must come first)");
+        }
+    }
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, nullptr, nullptr, nullptr);
     if (rc) return rc;
     *xyz_done = false;

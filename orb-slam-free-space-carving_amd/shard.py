@@ -5,17 +5,25 @@ covisible neighbours; K4 (InterKeyFrameDepthChecking, PM.cc:628-799) needs the n
 FINISHED {rho, sigma} maps (the reference gates on that at PM.cc:292-298).  So keyframes shard as
 contiguous blocks, one block per GPU, with exactly one exchange step between K3 and K4.
 
-Slot numbering is GLOBAL (slot == keyframe index) on every rank and the depth pool is one torch
-tensor [n_total, H, W, 2] handed to the engine as `ext_depth_pool`, so exchanged maps land where K4
-reads them and no re-indexing or staging copy is needed.  Two exchange forms:
+Slots are LOCAL: a rank's engine holds only the keyframes it touches -- its own block plus the
+input halo (the covisible neighbours that live on adjacent ranks) -- in ascending keyframe order, so
+the own block is a contiguous run of slots and device memory per rank does not grow with the world
+size.  plan()["slot"] maps a global keyframe index to the local slot.
 
-  halo (default)  each rank receives only the maps its K4 will read (the covisible neighbours that
-                  live on other ranks: N/2 keyframes from each adjacent block for an index-local
-                  covisibility graph) with batched point-to-point send/recv.  xGMI is point-to-point,
+Two exchange forms, two transports:
+
+  halo (default)  each rank receives only the maps its K4 will read (N/2 keyframes from each adjacent
+                  block for an index-local covisibility graph), point-to-point.  xGMI is point-to-point,
                   so this moves 2 x (N/2) x 8P bytes per rank over two direct links, independent of
                   the number of GPUs, and it is issued right after the boundary keyframes are
                   reconstructed so it overlaps the reconstruction of the interior ones.
-  allgather       the whole pool, in place (BASELINE.json's wording); (world-1) x block bytes per rank.
+  allgather       every rank's whole block (BASELINE.json's wording); (world-1) x block bytes per rank
+                  land in a gather buffer and the maps this rank reads are copied to their slots.
+
+  native          RCCL called by the engine itself (include/sdm_c.h sdm_exchange_* / sdm_allgather_depth):
+                  the C++ drop-in shards without Python; this module only hands over the lists.
+  torch           torch.distributed on the pool tensor (backend nccl = RCCL; gloo with host staging
+                  exists to rehearse the control flow with several ranks on ONE GPU or on CPU).
 """
 import torch
 import torch.distributed as dist
@@ -34,15 +42,19 @@ def owner_of(k, n_total, world):
 
 
 def plan(n_total, world, rank, n_nbr, neighbours_fn):
-    """Returns dict(first, count, own, nbrs, inputs, boundary, interior, recv, send).
+    """Returns a dict:
 
-    inputs   slots whose IMAGES this rank must hold = own block + its neighbours (input halo)
-    boundary own keyframes some OTHER rank's K4 reads (reconstruct these first, then exchange)
-    interior the rest of the own block
-    recv     {peer: sorted keyframes owned by peer that this rank's K4 reads}
-    send     {peer: sorted own keyframes that peer's K4 reads}
+    first, count  this rank's block of GLOBAL keyframe indices
+    own, nbrs     the block and each keyframe's covisible neighbours (global indices)
+    inputs        keyframes whose IMAGES this rank must hold = own block + its neighbours, ascending
+    slot          {global keyframe: local slot} over `inputs`; n_slots = len(inputs); first_slot
+    boundary      own keyframes some OTHER rank's K4 reads (reconstruct these first, then exchange)
+    interior      the rest of the own block
+    recv          {peer: ascending keyframes owned by peer that this rank's K4 reads}
+    send          {peer: ascending own keyframes that peer's K4 reads}
+    own_slots, nbr_slots, boundary_slots, interior_slots   the same lists in local slots
     Every rank derives every other rank's needs from the same deterministic neighbour function, so
-    send/recv lists match pairwise without negotiation."""
+    send/recv lists match pairwise (k-th send to a peer = that peer's k-th receive) without negotiation."""
     first, count = block_partition(n_total, world, rank)
     own = list(range(first, first + count))
     nbrs = [list(neighbours_fn(k, n_total, n_nbr)) for k in own]
@@ -68,8 +80,13 @@ def plan(n_total, world, rank, n_nbr, neighbours_fn):
     boundary = sorted({j for lst in send.values() for j in lst})
     bset = set(boundary)
     interior = [k for k in own if k not in bset]
-    return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=sorted(need), boundary=boundary,
-                interior=interior, recv=recv, send=send)
+    inputs = sorted(need)
+    slot = {k: i for i, k in enumerate(inputs)}
+    return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=inputs, boundary=boundary,
+                interior=interior, recv=recv, send=send, n_total=n_total, world=world, rank=rank,
+                slot=slot, n_slots=len(inputs), first_slot=slot[first],
+                own_slots=[slot[k] for k in own], nbr_slots=[[slot[j] for j in row] for row in nbrs],
+                boundary_slots=[slot[k] for k in boundary], interior_slots=[slot[k] for k in interior])
 
 
 def _runs(idx):
@@ -87,7 +104,7 @@ def _staged(pool, group):
     """True when the pool lives on a GPU but the process group is gloo, which has no device
     point-to-point: the exchange is then staged through host memory.  This exists to rehearse the
     multi-rank flow with several ranks on ONE GPU (tests/test_gpu_shard.py, bench.py with
-    SDM_BENCH_REHEARSE=1); production runs use RCCL ("nccl") and never take this path."""
+    SDM_BENCH_REHEARSE=1); production runs use RCCL and never take this path."""
     return pool.is_cuda and dist.get_backend(group) == "gloo"
 
 
@@ -101,18 +118,19 @@ class _StagedRecv:
 
 
 def exchange_halo_async(pool, pl, group=None):
-    """Starts the point-to-point exchange of the boundary maps; returns a list of work handles
-    (empty if there is nothing to exchange).  Contiguous runs of keyframes are sent/received as
-    views of `pool` (zero copy).  Call wait_all() before K4."""
+    """torch transport: starts the point-to-point exchange of the boundary maps; returns a list of work
+    handles (empty if there is nothing to exchange).  `pool` is indexed by LOCAL slot; contiguous runs
+    of keyframes are sent/received as views of it (zero copy).  Call wait_all() before K4."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return []
     staged = _staged(pool, group)
+    slot = pl["slot"]
     ops, recvs = [], []
     for peer in sorted(set(pl["send"]) | set(pl["recv"])):
-        for a, b in _runs(pl["send"].get(peer, [])):
+        for a, b in _runs([slot[k] for k in pl["send"].get(peer, [])]):
             src = pool[a:b].cpu() if staged else pool[a:b]  # .cpu() waits for the producing kernels
             ops.append(dist.P2POp(dist.isend, src, peer, group=group))
-        for a, b in _runs(pl["recv"].get(peer, [])):
+        for a, b in _runs([slot[k] for k in pl["recv"].get(peer, [])]):
             dst = torch.empty(pool[a:b].shape, dtype=pool.dtype) if staged else pool[a:b]
             recvs.append((len(ops), dst, pool[a:b]))
             ops.append(dist.P2POp(dist.irecv, dst, peer, group=group))
@@ -131,39 +149,82 @@ def wait_all(works):
         w.wait()
 
 
-def allgather_depth(pool, first, count, group=None):
-    """In-place all-gather of the depth pool: this rank has just written rows [first, first+count).
-    After the call every rank holds every keyframe's {rho, sigma}."""
+def allgather_depth(pool, pl, group=None, gather=None):
+    """torch transport: all-gather of every rank's block into `gather` ([n_total, H, W, 2], allocated on
+    first use and returned for reuse), then the maps this rank's K4 reads are copied to their local slots."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
-    if _staged(pool, group):
-        host = torch.empty(pool.shape, dtype=pool.dtype)
-        dist.all_gather_into_tensor(host, pool[first:first + count].cpu(), group=group)
-        pool.copy_(host)
-        return
-    mine = pool[first:first + count]
-    dist.all_gather_into_tensor(pool, mine, group=group)
+        return gather
+    staged = _staged(pool, group)
+    fs, cnt = pl["first_slot"], pl["count"]
+    shape = (pl["n_total"],) + tuple(pool.shape[1:])
+    if gather is None or tuple(gather.shape) != shape:
+        gather = torch.empty(shape, dtype=pool.dtype, device="cpu" if staged else pool.device)
+    mine = pool[fs:fs + cnt]
+    dist.all_gather_into_tensor(gather, mine.cpu() if staged else mine, group=group)
+    own = set(pl["own"])
+    for a, b in _runs([k for k in pl["inputs"] if k not in own]):
+        pool[pl["slot"][a]:pl["slot"][a] + (b - a)].copy_(gather[a:b])
+    return gather
 
 
-def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None):
+def halo_lists(pl):
+    """(send, recv) as lists of (peer, local slot) for the engine's native exchange"""
+    slot = pl["slot"]
+    send = [(p, slot[k]) for p in sorted(pl["send"]) for k in pl["send"][p]]
+    recv = [(p, slot[k]) for p in sorted(pl["recv"]) for k in pl["recv"][p]]
+    return send, recv
+
+
+def fetch_list(pl):
+    """[(index in the gathered sequence = global keyframe, local slot)] of the maps K4 reads from other ranks"""
+    own = set(pl["own"])
+    return [(k, pl["slot"][k]) for k in pl["inputs"] if k not in own]
+
+
+def setup_native_comm(eng, group=None):
+    """Builds the engine's RCCL communicator: rank 0 draws the unique id and the bytes travel over the
+    existing torch.distributed group (any channel would do; the C++ drop-in would use a file or MPI)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [eng.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    eng.comm_init(box[0], world, rank)
+
+
+_gather_cache = {}
+
+
+def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, transport="torch"):
     """One pass of the hot path over this rank's keyframe block (what bench.py times and the
     multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
     check (K4, snapshot form) + point set (K5; back-projected in the checking kernel).
 
     halo: boundary keyframes are reconstructed first; their maps travel to the adjacent ranks
     (point-to-point over xGMI) while the interior keyframes are reconstructed."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    own, nbrs = pl["own"], pl["nbrs"]
+    world = pl["world"]
+    own, nbrs = pl["own_slots"], pl["nbr_slots"]
     nb_of = dict(zip(own, nbrs))
-    boundary, interior = pl["boundary"], pl["interior"]
+    boundary, interior = pl["boundary_slots"], pl["interior_slots"]
+    native = transport == "native"
     if world > 1 and exchange == "halo" and boundary:
         eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
-        works = exchange_halo_async(pool, pl, group)
+        if native:
+            eng.exchange_halo_begin(*halo_lists(pl))
+        else:
+            works = exchange_halo_async(pool, pl, group)
         if interior:
             eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
-        wait_all(works)
+        if native:
+            eng.exchange_wait()
+        else:
+            wait_all(works)
+            eng.mark_depth_present([s for _, s in halo_lists(pl)[1]])
     else:
         eng.recon(own, nbrs, min_d, max_d)
         if world > 1:
-            allgather_depth(pool, pl["first"], pl["count"], group)
+            if native:
+                eng.allgather_depth(pl["first_slot"], pl["count"], fetch_list(pl))
+            else:
+                key = (id(pool), pl["n_total"])
+                _gather_cache[key] = allgather_depth(pool, pl, group, _gather_cache.get(key))
+                eng.mark_depth_present([s for _, s in fetch_list(pl)])
     eng.inter_check_pointset(own, nbrs, commit=False)  # K4 with K5 riding along (PM.cc:300-306)

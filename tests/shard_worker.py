@@ -3,6 +3,8 @@ torch.distributed.run with every rank on GPU 0 and a gloo group (host-staged exc
 so the multi-rank control flow -- block partition, input halo, boundary-first reconstruction, exchange
 of {rho,sigma} maps, inter-keyframe check against received maps -- runs on a one-GPU box.
 
+Slots are LOCAL (own block + input halo, shard.plan): the engine of a rank holds len(inputs) keyframes.
+
 usage: shard_worker.py OUT_DIR EXCHANGE N_TOTAL N_NBR"""
 import os
 import sys
@@ -31,23 +33,24 @@ def main():
     pl = pkg.shard.plan(n_total, world, rank, n_nbr, scene.neighbours)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32, device="cuda")
-    eng = pkg.Engine(W, H, n_total, max_neighbours=n_nbr, device=0, batch_capacity=n_total, with_pointset=True,
-                     ext_depth_pool=pool.data_ptr(), stream=stream.cuda_stream)
+    slot = pl["slot"]
+    pool = torch.zeros((pl["n_slots"], H, W, 2), dtype=torch.float32, device="cuda")
+    eng = pkg.Engine(W, H, pl["n_slots"], max_neighbours=n_nbr, device=0, batch_capacity=pl["n_slots"],
+                     with_pointset=True, ext_depth_pool=pool.data_ptr(), stream=stream.cuda_stream)
     for k in pl["inputs"]:  # own block + input halo only
         im, _ = scene.render(k, device="cuda")
         torch.cuda.synchronize()
-        eng.upload_image_device(k, im.data_ptr(), scene.K(), scene.Tcw(k))
+        eng.upload_image_device(slot[k], im.data_ptr(), scene.K(), scene.Tcw(k))
     min_d, max_d = scene.depth_prior()
     for _ in range(2):  # twice: the second pass must not depend on state left by the first
-        pkg.shard.pipeline_step(eng, pool, pl, min_d, max_d, exchange)
+        pkg.shard.pipeline_step(eng, pool, pl, min_d, max_d, exchange, transport="torch")
     torch.cuda.synchronize()
     out = {"own": np.array(pl["own"]), "recv": np.array(sorted(j for v in pl["recv"].values() for j in v))}
     for k in pl["own"]:
-        r, s = eng.download_depth(k)
+        r, s = eng.download_depth(slot[k])
         out["rho%d" % k], out["sig%d" % k] = r, s
-        out["chk%d" % k] = eng.download_checked(k)
-        out["xyz%d" % k] = eng.download_pointset(k)
+        out["chk%d" % k] = eng.download_checked(slot[k])
+        out["xyz%d" % k] = eng.download_pointset(slot[k])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
     dist.barrier()
     eng.close()

@@ -55,6 +55,10 @@ def test_shard_plan_covers_everything(pkg):
             assert row == nb(k, n_total, n)
             assert set(row) <= set(pl["inputs"])       # input halo is local
         assert set(pl["own"]) <= set(pl["inputs"])
+        # local slots: ascending keyframe order, own block contiguous
+        assert [pl["slot"][k] for k in pl["inputs"]] == list(range(pl["n_slots"]))
+        assert pl["own_slots"] == list(range(pl["first_slot"], pl["first_slot"] + pl["count"]))
+        assert pl["nbr_slots"] == [[pl["slot"][j] for j in row] for row in pl["nbrs"]]
         assert len(pl["inputs"]) <= 8 + n              # halo is at most n/2 each side (+ clipping)
     assert sorted(seen) == list(range(n_total))
     with pytest.raises(ValueError):
@@ -75,27 +79,24 @@ def _worker(rank, world, port, n_total, H, W, out, mode="allgather", n_nbr=4):
     pkg = sdm_pkg.load()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     pl = pkg.shard.plan(n_total, world, rank, n_nbr, pkg.synth.Scene.neighbours)
-    pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32)
+    slot = pl["slot"]
+    pool = torch.zeros((pl["n_slots"], H, W, 2), dtype=torch.float32)  # LOCAL slots: own block + halo only
     # stand-in for K1-K3: this rank fills only its own block with a recognisable pattern
     for k in pl["own"]:
-        pool[k, :, :, 0] = k + 0.25
-        pool[k, :, :, 1] = -(k + 0.5)
+        pool[slot[k], :, :, 0] = k + 0.25
+        pool[slot[k], :, :, 1] = -(k + 0.5)
     if mode == "allgather":
-        pkg.shard.allgather_depth(pool, pl["first"], pl["count"])
-        expect = range(n_total)
+        pkg.shard.allgather_depth(pool, pl)
     else:
         pkg.shard.wait_all(pkg.shard.exchange_halo_async(pool, pl))
-        expect = pl["inputs"]
-    ok = True
-    for k in range(n_total):
-        if k in expect:
-            ok = ok and bool((pool[k, :, :, 0] == k + 0.25).all()) and bool((pool[k, :, :, 1] == -(k + 0.5)).all())
-        else:
-            ok = ok and not bool(pool[k].any())  # halo mode moves nothing it does not need
-    # every neighbour a rank's K4 will read is now present
-    for row in pl["nbrs"]:
-        for j in row:
-            ok = ok and float(pool[j, 0, 0, 0]) == j + 0.25
+    ok = pl["n_slots"] <= pl["count"] + n_nbr  # memory per rank does not grow with the world size
+    ok = ok and pl["own_slots"] == list(range(pl["first_slot"], pl["first_slot"] + pl["count"]))
+    for k in pl["inputs"]:  # every keyframe this rank touches now holds its owner's map, in its slot
+        ok = ok and bool((pool[slot[k], :, :, 0] == k + 0.25).all()) and bool((pool[slot[k], :, :, 1] == -(k + 0.5)).all())
+    # every neighbour a rank's K4 will read is present
+    for row in pl["nbr_slots"]:
+        for s in row:
+            ok = ok and float(pool[s, 0, 0, 1]) < 0
     out[rank] = ok
     dist.destroy_process_group()
 
@@ -126,6 +127,10 @@ def test_halo_plan_is_pairwise_consistent(pkg):
                 assert plans[q]["recv"][r] == lst
             got = set(pl["own"]) | {j for lst in pl["recv"].values() for j in lst}
             assert got == set(pl["inputs"])
+            send, recv = shard.halo_lists(pl)
+            assert len(send) == sum(len(v) for v in pl["send"].values())
+            assert sorted(s for _, s in recv) == sorted(pl["slot"][k] for k in pl["inputs"] if k not in pl["own"])
+            assert shard.fetch_list(pl) == [(k, pl["slot"][k]) for k in pl["inputs"] if k not in pl["own"]]
         # index-local covisibility: only adjacent blocks talk, N/2 keyframes each way
         mid = plans[world // 2] if (world > 2 and n_total // world >= n // 2) else None
         if mid is not None:

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/final
 timeout -k 10 300 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err || echo "bench failed"
 tail -c 400 gpurun_out/final/bench.json
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -- python3 bench.py --steps 10 --warmup 2 --cpu-kfs 0 > gpurun_out/final/kt.log 2>&1 || echo "kernel trace failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -- python3 bench.py --steps 10 --warmup 2 --cpu-kfs 0 --no-extra > gpurun_out/final/kt.log 2>&1 || echo "kernel trace failed"
 f=$(find gpurun_out/final/kt -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then (head -1 "$f"; grep "sdm::" "$f") > gpurun_out/final/kernel_stats.csv; fi
 python3 tools/kstats.py gpurun_out/final/kt

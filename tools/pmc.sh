@@ -13,7 +13,7 @@ i=0
 while IFS= read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --cpu-kfs 0 --no-stats "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed"
+  timeout -k 10 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --cpu-kfs 0 --no-stats --no-extra "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed"
 done <<'GROUPS'
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum
@@ -24,6 +24,6 @@ TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum T
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAVES GRBM_GUI_ACTIVE
 GROUPS
-python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+PMC_BENCH_ARGS="$*" python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 rm -rf "$OUT"/p[0-9]*
 cat "$OUT/summary.txt"

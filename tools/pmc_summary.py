@@ -36,5 +36,18 @@ if k1:
                "FETCH_SIZE_KB": c.get("FETCH_SIZE"), "WRITE_SIZE_KB": c.get("WRITE_SIZE"),
                "method": "32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B (+ 64*WRREQ_64B + 32*other WRREQ), "
                          "TCC_EA0 counters summed over channels, averaged over launches"}
+        # tie the figure to the build and workload it was measured on (bench.py only reports a matching one)
+        import argparse, os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--kfs", type=int, default=64)
+        ap.add_argument("--nbrs", type=int, default=20)
+        ap.add_argument("--res", default="480p")
+        ap.add_argument("--disparity", type=float, default=2.6)
+        a, _ = ap.parse_known_args(os.environ.get("PMC_BENCH_ARGS", "").split())
+        out["workload"] = {"res": a.res, "kfs": a.kfs, "nbrs": a.nbrs, "disparity": a.disparity}
+        out["src_hash"] = bench.source_hash()
+        out["source"] = "tools/pmc.sh (rocprofv3 --pmc, one counter group per pass)"
         json.dump(out, open(root + "/traffic.json", "w"), indent=1)
         print("traffic.json:", json.dumps(out))
