@@ -456,7 +456,9 @@ def test_neighbour_count_edges(pkg, oracle, gpu_ok, n):
     refs = [0, n_kf // 2, n_kf - 1]
     nbrs = [seq.neighbours(k, n) for k in refs]
     eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
-    eng.inter_check(refs, nbrs)
+    with pytest.raises(pkg.SdmError) as ei:  # neighbours without a depth map: the reference's gate, PM.cc:292-298
+        eng.inter_check(refs, nbrs)
+    assert ei.value.code == 4
     fused = 0
     for i, k in enumerate(refs):
         r, s, _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[i]], None, seq.min_depth, seq.max_depth)
@@ -678,6 +680,7 @@ def test_table_cache_alternating_calls(pkg, oracle, gpu_ok, seq_mid):
     rng = np.random.default_rng(3)
     eng = make_engine(pkg, seq, n, with_pointset=True)
     all_k = list(range(seq.n_kf))
+    eng.mark_depth_present(all_k)  # the (still zero) maps of not-yet-reconstructed neighbours are read on purpose
     groups = [all_k[:3], all_k[3:6], all_k[1:5], all_k[::2], all_k[5:], all_k[2:4]]
     poses = {k: seq.Tcw[k].copy() for k in all_k}
     lam = 8.0

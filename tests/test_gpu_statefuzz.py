@@ -26,6 +26,7 @@ class Model:
         self.chk = {k: z(H, W) for k in range(n_kf)}
         self.xyz = {k: z(H, 3 * W) for k in range(n_kf)}
         self.has_chk = {k: False for k in range(n_kf)}
+        self.has_depth = {k: False for k in range(n_kf)}  # kf->semidense_flag_ (PM.cc:244, gate at :292-298)
 
     def kf(self, k):
         g, th, s = self.der[k]
@@ -38,6 +39,7 @@ class Model:
             m[k] = np.zeros((self.H, self.W), np.float32)
         self.xyz[k] = np.zeros((self.H, 3 * self.W), np.float32)
         self.has_chk[k] = False
+        self.has_depth[k] = False
 
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("SDM_FUZZ_FIRST", "1")), int(os.environ.get("SDM_FUZZ_FIRST", "1")) +
@@ -51,7 +53,7 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
     m = Model(oracle, W, H, n_kf, K)
     lam = 8.0
     oracle.params.lambdaG = lam
-    kept = 0
+    kept = refused = 0
     try:
         for k in range(n_kf):
             eng.upload_image(k, seq.im[k], K, seq.Tcw[k])
@@ -71,10 +73,12 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
                 eng.recon(refs, nbrs, mind, maxd)
                 for k, nb in zip(refs, nbrs):
                     m.rho[k], m.sig[k], _ = oracle.semi_dense_recon(m.kf(k), [m.kf(j) for j in nb], None, mind, maxd)
+                    m.has_depth[k] = True
             elif op == "search_fuse":
                 eng.search_fuse(refs, nbrs, mind, maxd)
                 for k, nb in zip(refs, nbrs):
                     m.rho[k], m.sig[k], _ = oracle.recon_search_fuse(m.kf(k), [m.kf(j) for j in nb], None, mind, maxd)
+                    m.has_depth[k] = True
             elif op == "intra_check":
                 eng.intra_check(refs)
                 for k in refs:
@@ -85,6 +89,14 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
                     m.rho[k], m.sig[k] = oracle.intra_grow(m.rho[k], m.sig[k], m.der[k][0])
             elif op in ("inter", "inter_commit", "fused"):
                 commit = op == "inter_commit"
+                if not all(m.has_depth[k] for k in refs) or not all(m.has_depth[j] for nb in nbrs for j in nb):
+                    # the reference's gate (PM.cc:292-298): a keyframe or neighbour without a depth map is a caller
+                    # error in the C ABI -- SDM_ESTATE, and nothing changes
+                    with pytest.raises(pkg.SdmError) as ei:
+                        (eng.inter_check_pointset if op == "fused" else eng.inter_check)(refs, nbrs)
+                    assert ei.value.code == 4
+                    refused += 1
+                    continue
                 if op == "fused":
                     eng.inter_check_pointset(refs, nbrs)
                 else:
@@ -119,6 +131,7 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
                 r[:, :2] = r[:, -2:] = 0
                 eng.upload_depth(k, r, s)
                 m.rho[k], m.sig[k] = r, s
+                m.has_depth[k] = True
             elif op == "assume":
                 # legitimate only for maps ({rho, sigma}) that are zero outside the current list
                 def zero_outside(k):
@@ -129,6 +142,8 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
                 touched = ok
                 if ok:
                     eng.assume_pipeline_maps(ok)
+                    for k in ok:
+                        m.has_depth[k] = True
             elif op == "set_pose":
                 k = refs[0]
                 touched = [k]
