@@ -137,6 +137,28 @@ public:
                                double max_sigma = 0.01);
     bool ok() const { return ctx_ != nullptr; }
 
+    /* ---- device-slot cache contract (keyframes are cached by address) --------------------------------------
+     * Forget: the integrator is about to delete (or has culled) the keyframe -- drops its device slot so that a
+     * new KeyFrame allocated at the same address starts clean.  Call it where the fork erases keyframes
+     * (src/KeyFrame.cc:449-497 SetBadFlag / Map::EraseKeyFrame, src/Map.cc:55-66).
+     * InvalidateDepth: the integrator edited kf->depth_map_ / depth_sigma_ on the host (a sigma-threshold pass,
+     * a manual reset): the next call that needs the map uploads the host copy again. */
+    void Forget(sdm::KeyFrame* kf);
+    void InvalidateDepth(sdm::KeyFrame* kf);
+
+    /* ---- multi-GPU: one process per GPU, keyframes sharded in contiguous blocks -------------
+     * InitSharding builds the engine's RCCL communicator from a 128-byte unique id (sdm_comm_unique_id on rank 0,
+     * handed to the other ranks through any channel: a file, MPI, a socket).  world == 1 needs no id.
+     * SemiDenseReconBlock runs the whole path for this rank's block all[first, first+count) of the map's
+     * keyframes (`all` and the covisibility lists identical on every rank; images needed only for the block and
+     * its covisible neighbours): SemiDenseRecon of the keyframes other ranks read -> their {rho,sigma} maps
+     * leave over xGMI while the remaining keyframes are reconstructed -> InterKeyFrameDepthChecking against the
+     * finished maps of all neighbours (snapshot order: every keyframe is checked against the neighbours' maps as
+     * SemiDenseRecon left them, the order that shards) -> UpdateSemiDensePointSet.  Collective:
+     * every rank calls it once per pass with its own block. */
+    bool InitSharding(const unsigned char* comm_id, int world, int rank);
+    void SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count);
+
 private:
     int SlotOf(sdm::KeyFrame* kf);   /* uploads the keyframe on first use */
     bool Ensure(int W, int H);

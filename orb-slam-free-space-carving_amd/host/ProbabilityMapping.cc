@@ -113,6 +113,22 @@ int ProbabilityMapping::SlotOf(sdm::KeyFrame* kf)
     return slot;
 }
 
+void ProbabilityMapping::Forget(sdm::KeyFrame* kf)
+{
+    auto it = slots_.find(kf);
+    if (it == slots_.end()) return;
+    slot_owner_[it->second] = nullptr;
+    slot_use_[it->second] = 0;
+    depth_on_device_.erase(kf);
+    slots_.erase(it);
+}
+
+void ProbabilityMapping::InvalidateDepth(sdm::KeyFrame* kf)
+{
+    auto it = depth_on_device_.find(kf);
+    if (it != depth_on_device_.end()) it->second = 0;
+}
+
 // make the slot's depth map equal to the keyframe's host maps
 void ProbabilityMapping::PushDepth(sdm::KeyFrame* kf, int slot)
 {
@@ -392,4 +408,170 @@ long ProbabilityMapping::AppendTranscriptEntry(sdm::KeyFrame* kf, int camIndex, 
         }
     out << "}" << std::endl;
     return n;
+}
+
+// ---- multi-GPU block driver -----------------------------------------------------------------
+bool ProbabilityMapping::InitSharding(const unsigned char* comm_id, int world, int rank)
+{
+    if (!ctx_) {
+        std::cerr << "ProbabilityMapping::InitSharding: no device context yet (upload a keyframe first or size the "
+                     "context with SemiDenseReconBlock)" << std::endl;
+        return false;
+    }
+    if (sdm_comm_init(ctx_, comm_id, world, rank) != SDM_OK) {
+        report("InitSharding");
+        return false;
+    }
+    return true;
+}
+
+void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count)
+{
+    const int n_all = (int)all.size();
+    if (count < 1 || first < 0 || first + count > n_all) {
+        std::cerr << "ProbabilityMapping::SemiDenseReconBlock: block out of range" << std::endl;
+        return;
+    }
+    if (!Ensure(all[first]->im_.cols, all[first]->im_.rows)) return;
+    int world = 1, rank = 0;
+    sdm_comm_info(ctx_, &world, &rank);
+    if (world > 1 && (n_all != world * count || first != rank * count)) {
+        std::cerr << "ProbabilityMapping::SemiDenseReconBlock: blocks must be equal and contiguous (rank*count)" << std::endl;
+        return;
+    }
+    std::map<sdm::KeyFrame*, int> index;
+    for (int i = 0; i < n_all; i++) index[all[i]] = i;
+    auto own = [&](int i) { return i >= first && i < first + count; };
+    // neighbours of a keyframe as global indices; empty = the keyframe is skipped (PM.cc:141,160)
+    auto nbr_idx = [&](int i) {
+        std::vector<int> out;
+        sdm::KeyFrame* kf = all[i];
+        if (kf->isBad()) return out;
+        std::vector<sdm::KeyFrame*> nb = PickNeighbours(kf);
+        if ((int)nb.size() < opt_.covisN) return out;
+        for (sdm::KeyFrame* p : nb) {
+            auto it = index.find(p);
+            if (it == index.end()) return std::vector<int>();
+            out.push_back(it->second);
+        }
+        return out;
+    };
+    // this rank's work list and the keyframes whose images it needs
+    std::vector<int> refs;
+    std::vector<std::vector<int>> nbrs;
+    std::vector<char> needed(n_all, 0);
+    for (int i = first; i < first + count; i++) {
+        needed[i] = 1;
+        std::vector<int> nb = all[i]->semidense_flag_ ? std::vector<int>() : nbr_idx(i);
+        if (nb.empty()) continue;
+        refs.push_back(i);
+        nbrs.push_back(nb);
+        for (int j : nb) needed[j] = 1;
+    }
+    int n_needed = 0;
+    for (int i = 0; i < n_all; i++) n_needed += needed[i];
+    if (n_needed > (int)slot_owner_.size()) {
+        std::cerr << "ProbabilityMapping::SemiDenseReconBlock: " << n_needed << " keyframes (block + covisible halo) "
+                  << "exceed Options::max_keyframes = " << slot_owner_.size() << std::endl;
+        return;
+    }
+    std::vector<int> slot(n_all, -1);
+    for (int i = 0; i < n_all; i++)
+        if (needed[i] && (slot[i] = SlotOf(all[i])) < 0) return;
+    {   // own keyframes that are not reconstructed in this pass still answer a peer's request (with the map they have)
+        std::vector<int> s;
+        for (int i = first; i < first + count; i++) {
+            if (all[i]->semidense_flag_) PushDepth(all[i], slot[i]);  // a fresh slot already holds the zero map
+            s.push_back(slot[i]);
+        }
+        if (sdm_mark_depth_present(ctx_, (int)s.size(), s.data()) != SDM_OK) report("SemiDenseReconBlock");
+    }
+    // what leaves and what arrives: derived identically on every rank from the replicated covisibility lists
+    std::vector<int> send_peer, send_slot, recv_peer, recv_slot;
+    std::vector<char> is_boundary(n_all, 0);
+    if (world > 1) {
+        for (int q = 0; q < world; q++) {
+            if (q == rank) continue;
+            std::vector<char> wanted(n_all, 0);
+            for (int i = q * count; i < (q + 1) * count; i++)
+                if (!all[i]->semidense_flag_)
+                    for (int j : nbr_idx(i))
+                        if (own(j)) wanted[j] = 1;
+            for (int j = first; j < first + count; j++)
+                if (wanted[j]) {
+                    send_peer.push_back(q);
+                    send_slot.push_back(slot[j]);
+                    is_boundary[j] = 1;
+                }
+        }
+        for (int j = 0; j < n_all; j++)
+            if (needed[j] && !own(j)) {
+                recv_peer.push_back(j / count);
+                recv_slot.push_back(slot[j]);
+            }
+    }
+    // per-reference constants: depth prior (PM.cc:184) and median in-plane rotations (PM.cc:170-179)
+    const int n = opt_.covisN;
+    auto run_recon = [&](bool boundary) {
+        std::vector<int> r, ns;
+        std::vector<float> rot, mind, maxd;
+        for (size_t a = 0; a < refs.size(); a++) {
+            if ((is_boundary[refs[a]] != 0) != boundary) continue;
+            sdm::KeyFrame* kf = all[refs[a]];
+            r.push_back(slot[refs[a]]);
+            float mn = 0.f, mx = 0.f;
+            StereoSearchConstraints(kf, &mn, &mx);
+            mind.push_back(mn);
+            maxd.push_back(mx);
+            for (int j : nbrs[a]) {
+                sdm::KeyFrame* k2 = all[j];
+                ns.push_back(slot[j]);
+                rot.push_back(sdm_median_rot_in_plane(
+                    kf->map_point_ids.data(), kf->keypoint_angles.data(),
+                    (int)std::min(kf->map_point_ids.size(), kf->keypoint_angles.size()), k2->map_point_ids.data(),
+                    k2->keypoint_angles.data(), (int)std::min(k2->map_point_ids.size(), k2->keypoint_angles.size())));
+            }
+        }
+        if (r.empty()) return true;
+        if (sdm_recon(ctx_, (int)r.size(), r.data(), n, ns.data(), rot.data(), mind.data(), maxd.data()) != SDM_OK) {
+            report("SemiDenseReconBlock");
+            return false;
+        }
+        return true;
+    };
+    if (!run_recon(true)) return;  // the keyframes other ranks read first ...
+    if (sdm_exchange_halo_begin(ctx_, (int)send_peer.size(), send_peer.data(), send_slot.data(), (int)recv_peer.size(),
+                                recv_peer.data(), recv_slot.data()) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        return;
+    }
+    if (!run_recon(false)) return;  // ... the rest while those maps travel
+    if (sdm_exchange_wait(ctx_) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        return;
+    }
+    if (refs.empty()) return;
+    std::vector<int> r, ns;
+    for (size_t a = 0; a < refs.size(); a++) {
+        r.push_back(slot[refs[a]]);
+        for (int j : nbrs[a]) ns.push_back(slot[j]);
+    }
+    // the maps as SemiDenseRecon left them (PM.cc:244), then PM.cc:300-306 for the whole block, snapshot order
+    for (size_t a = 0; a < refs.size(); a++) {
+        sdm::KeyFrame* kf = all[refs[a]];
+        if (sdm_download_depth(ctx_, r[a], kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK) report("SemiDenseReconBlock");
+        kf->semidense_flag_ = true;
+    }
+    if (sdm_inter_check_pointset(ctx_, (int)r.size(), r.data(), n, ns.data(), /*commit=*/0) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        return;
+    }
+    for (size_t a = 0; a < refs.size(); a++) {
+        sdm::KeyFrame* kf = all[refs[a]];
+        if (sdm_download_checked(ctx_, r[a], kf->depth_map_.ptr()) != SDM_OK ||
+            sdm_download_pointset(ctx_, r[a], kf->SemiDensePointSets_.ptr()) != SDM_OK)
+            report("SemiDenseReconBlock");
+        depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
+        kf->interKF_depth_flag_ = true;  // PM.cc:306
+    }
 }

@@ -1,0 +1,85 @@
+// Drives ProbabilityMapping::SemiDenseReconBlock -- the batch / multi-GPU form of the class -- on
+// one rank: the whole sequence is this rank's block, the exchange calls are no-ops (world size 1), and the result must
+// be the snapshot-order pipeline of the CPU oracle (tests/test_gpu_cpp_class.py).  Also exercises the slot-cache
+// contract: InvalidateDepth (host map edited -> re-uploaded) and Forget (slot dropped -> keyframe re-uploaded).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sdm/ProbabilityMapping.h"
+
+static void rd(FILE* f, void* p, size_t n)
+{
+    if (fread(p, 1, n, f) != n) {
+        fprintf(stderr, "short read\n");
+        exit(2);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int hdr[4];
+    rd(f, hdr, sizeof(hdr));
+    const int W = hdr[0], H = hdr[1], n_kf = hdr[2], covisN = hdr[3];
+    std::vector<sdm::KeyFrame> kfs(n_kf);
+    std::vector<std::vector<int>> covis(n_kf);
+    for (int k = 0; k < n_kf; k++) {
+        sdm::KeyFrame& kf = kfs[k];
+        kf.mnId = k;
+        kf.im_ = sdm::Mat<uint8_t>(H, W);
+        rd(f, kf.im_.ptr(), (size_t)W * H);
+        float K[4];
+        rd(f, K, sizeof(K));
+        kf.fx = K[0];
+        kf.fy = K[1];
+        kf.cx = K[2];
+        kf.cy = K[3];
+        rd(f, kf.Tcw, sizeof(float) * 12);
+        int nc;
+        rd(f, &nc, sizeof(int));
+        covis[k].resize(nc);
+        rd(f, covis[k].data(), sizeof(int) * nc);
+        int nd;
+        rd(f, &nd, sizeof(int));
+        kf.point_depths.resize(nd);
+        rd(f, kf.point_depths.data(), sizeof(float) * nd);
+    }
+    fclose(f);
+    sdm::Map map;
+    for (int k = 0; k < n_kf; k++) {
+        for (int j : covis[k]) kfs[k].covisible.push_back(&kfs[j]);
+        map.keyframes.push_back(&kfs[k]);
+    }
+    sdm::Options opt;
+    opt.covisN = covisN;
+    opt.max_keyframes = n_kf;
+    ProbabilityMapping pm(&map, opt);
+    pm.SemiDenseReconBlock(map.keyframes, 0, n_kf);  // sizes the context, runs K1-K5 for the block
+    if (!pm.ok()) return 3;
+    if (!pm.InitSharding(nullptr, 1, 0)) return 4;   // world size 1: accepted, nothing to build
+    pm.SemiDenseReconBlock(map.keyframes, 0, n_kf);  // second pass: everything already reconstructed -> no work, no change
+
+    // slot-cache contract
+    std::vector<float> xyz1 = kfs[1].SemiDensePointSets_.data, xyz2 = kfs[2].SemiDensePointSets_.data;
+    pm.InvalidateDepth(&kfs[1]);
+    pm.UpdateSemiDensePointSet(&kfs[1]);  // from the host (checked) map, uploaded again
+    pm.Forget(&kfs[2]);
+    pm.UpdateSemiDensePointSet(&kfs[2]);  // keyframe uploaded again into a fresh slot
+    int same = (xyz1 == kfs[1].SemiDensePointSets_.data) && (xyz2 == kfs[2].SemiDensePointSets_.data);
+
+    FILE* o = fopen(argv[2], "wb");
+    if (!o) return 2;
+    for (int k = 0; k < n_kf; k++) {
+        int flags[3] = {kfs[k].semidense_flag_, kfs[k].interKF_depth_flag_, same};
+        fwrite(flags, sizeof(int), 3, o);
+        fwrite(kfs[k].depth_map_.ptr(), sizeof(float), (size_t)W * H, o);
+        fwrite(kfs[k].depth_sigma_.ptr(), sizeof(float), (size_t)W * H, o);
+        fwrite(kfs[k].SemiDensePointSets_.ptr(), sizeof(float), (size_t)3 * W * H, o);
+    }
+    fclose(o);
+    return 0;
+}

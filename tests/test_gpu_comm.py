@@ -1,0 +1,69 @@
+"""GPU: the native exchange entry points of the C ABI (include/sdm_c.h sdm_comm_* / sdm_exchange_* /
+sdm_allgather_depth) at world size 1, where they must be exact no-ops, plus their argument checking.  The RCCL
+transport between GPUs cannot run on a one-GPU box (RCCL refuses two ranks on one device): UNMEASURED ON HARDWARE
+until the driver's multi-GPU run; the multi-rank control flow is covered with the torch/gloo transport in
+test_gpu_shard.py and the plan/list logic on CPU in test_shard_synth.py."""
+import numpy as np
+import pytest
+
+from common import Sequence, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_world1_exchange_is_a_noop(pkg, oracle, gpu_ok):
+    seq = Sequence(pkg, oracle, 96, 72, 8, 0x5EED0C11)
+    n = 5
+    eng = pkg.Engine(seq.W, seq.H, seq.n_kf, max_neighbours=n)
+    seq.upload(eng, device_prepass=True)
+    assert eng.comm_info() == (1, 0)
+    eng.comm_init(None, 1, 0)  # world size 1 needs no unique id and never loads RCCL
+    assert eng.comm_info() == (1, 0)
+    pl = pkg.shard.plan(seq.n_kf, 1, 0, n, seq.scene.neighbours)
+    assert pl["n_slots"] == seq.n_kf and pkg.shard.halo_lists(pl) == ([], []) and pkg.shard.fetch_list(pl) == []
+    refs, nbrs = pl["own_slots"], pl["nbr_slots"]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    before = [eng.download_depth(k) for k in refs]
+    eng.exchange_halo_begin([], [])
+    eng.exchange_wait()
+    eng.exchange_halo([], [])
+    eng.allgather_depth(0, seq.n_kf, fetch=[])      # gathered-buffer form
+    eng.allgather_depth(0, seq.n_kf, fetch=None)    # in-place form (slot == global keyframe index)
+    for k, (r, s) in zip(refs, before):
+        g = eng.download_depth(k)
+        assert_bit_equal(g[0], r)
+        assert_bit_equal(g[1], s)
+    # the whole step through the native transport == the plain calls
+    for exch in ("halo", "allgather"):
+        pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native")
+        chk = [eng.download_checked(k) for k in refs]
+        eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+        eng.inter_check(refs, nbrs)
+        for k in refs:
+            assert_bit_equal(eng.download_checked(k), chk[k], "checked rho kf %d (%s)" % (k, exch))
+    eng.comm_destroy()
+    eng.close()
+
+
+def test_exchange_argument_checks(pkg, gpu_ok):
+    eng = pkg.Engine(64, 48, 4, max_neighbours=3)
+    with pytest.raises(pkg.SdmError) as e:  # world size 1 has no peers
+        eng.exchange_halo_begin([(1, 0)], [])
+    assert e.value.code == 1
+    with pytest.raises(pkg.SdmError) as e:  # block beyond the slots
+        eng.allgather_depth(2, 3, fetch=[])
+    assert e.value.code == 1
+    with pytest.raises(pkg.SdmError) as e:  # block slots hold no depth map yet
+        eng.allgather_depth(0, 2, fetch=[])
+    assert e.value.code == 4
+    with pytest.raises(pkg.SdmError) as e:
+        eng.comm_init(None, 2, 5)
+    assert e.value.code == 1
+    with pytest.raises(pkg.SdmError) as e:  # a multi-rank communicator needs an id
+        eng.comm_init(None, 2, 0)
+    assert e.value.code == 1
+    eng.mark_depth_present([0, 1])
+    eng.allgather_depth(0, 2, fetch=[])
+    with pytest.raises(pkg.SdmError):
+        eng.mark_depth_present([7])
+    eng.close()

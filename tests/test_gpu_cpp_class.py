@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_driver(pkg):
+def build_driver(pkg, name="test_pm_class"):
     pkg.build_mod.build_all()
     lib = os.path.join(ROOT, "orb-slam-free-space-carving_amd", "lib")
-    exe = os.path.join(lib, "test_pm_class")
-    src = os.path.join(ROOT, "tests", "cpp", "test_pm_class.cc")
+    exe = os.path.join(lib, name)
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src),
                                                                os.path.getmtime(os.path.join(lib, "libsdm_pm.so"))):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
@@ -139,3 +139,56 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path, n_kf, 
     assert got[:-1] == want
     if n >= 7:  # with few neighbours hardly any point passes the sigma filter; the text comparison above still holds
         assert sum(1 for l in want if l.startswith("new point")) > 50
+
+
+def write_blob(path, seq, n_kf, n, depths):
+    with open(path, "wb") as f:
+        np.array([seq.W, seq.H, n_kf, n], np.int32).tofile(f)
+        for k in range(n_kf):
+            seq.im[k].tofile(f)
+            seq.K.astype(np.float32).tofile(f)
+            seq.Tcw[k].astype(np.float32).tofile(f)
+            cov = np.array(seq.scene.neighbours(k, n_kf, n_kf - 1), np.int32)
+            np.array([len(cov)], np.int32).tofile(f)
+            cov.tofile(f)
+            np.array([len(depths[k])], np.int32).tofile(f)
+            depths[k].tofile(f)
+
+
+def test_cpp_class_block_driver_matches_oracle_snapshot(pkg, oracle, gpu_ok, tmp_path):
+    """ProbabilityMapping::SemiDenseReconBlock -- the batch / sharded form (the whole sequence as one rank's block,
+    exchange calls are world-size-1 no-ops) -- equals the oracle's snapshot-order pipeline bit for bit; Forget and
+    InvalidateDepth leave results unchanged"""
+    exe = build_driver(pkg, "test_pm_block")
+    n_kf, n = 10, 7
+    seq = Sequence(pkg, oracle, 96, 72, n_kf, 0x5EED0E02)
+    W, H = seq.W, seq.H
+    rng = np.random.default_rng(1)
+    depths = [(1.0 + 0.1 * rng.standard_normal(200)).astype(np.float32) for _ in range(n_kf)]
+    blob, out = tmp_path / "in.bin", tmp_path / "out.bin"
+    write_blob(blob, seq, n_kf, n, depths)
+    subprocess.check_call([exe, str(blob), str(out)])
+    nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
+    rho, sig = {}, {}
+    for k in range(n_kf):
+        mn, mx = oracle.stereo_search_constraints(depths[k])
+        rho[k], sig[k], _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, mn, mx)
+    raw = np.fromfile(out, dtype=np.uint8)
+    off, kept = 0, 0
+    for k in range(n_kf):
+        flags = raw[off:off + 12].view(np.int32)
+        off += 12
+        assert list(flags) == [1, 1, 1], (k, flags)
+        chk = oracle.inter_check(seq.okf[k], rho[k], [seq.okf[j] for j in nbrs[k]], [rho[j] for j in nbrs[k]],
+                                 [sig[j] for j in nbrs[k]])
+        got = raw[off:off + 4 * W * H].view(np.float32).reshape(H, W)
+        off += 4 * W * H
+        assert_bit_equal(got, chk, "depth_map_ (checked, snapshot order) kf %d" % k)
+        got = raw[off:off + 4 * W * H].view(np.float32).reshape(H, W)
+        off += 4 * W * H
+        assert_bit_equal(got, sig[k], "depth_sigma_ kf %d" % k)
+        got = raw[off:off + 12 * W * H].view(np.float32).reshape(H, 3 * W)
+        off += 12 * W * H
+        assert_bit_equal(got, oracle.pointset(seq.okf[k], chk), "SemiDensePointSets_ kf %d" % k)
+        kept += int((chk > 1e-6).sum())
+    assert kept > 1000
