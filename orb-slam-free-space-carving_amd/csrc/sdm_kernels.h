@@ -374,7 +374,7 @@ __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
-           sizeof(unsigned long long) * K1_BLOCK;
+           sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned) * K1_PX;
 }
 
 #ifndef SDM_K1_LB
@@ -398,6 +398,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
     const int cnt_words = (n + 3) >> 2;
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
+    unsigned* cnt0 = reinterpret_cast<unsigned*>(pmask + K1_BLOCK);  // [64] size of the FIRST hypothesis' compatible set
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -453,6 +454,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         sgm[j * K1_PX + p] = h.y;
     }
     for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
+    if (w == 0) cnt0[p] = 0u;
     pmask[tid] = mymask;
     __syncthreads();
 
@@ -471,30 +473,63 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
 #else
     const int nh = __popcll(vm);
 #endif
-    if (nh > prm.lambdaN) {  // PM.cc:221
-        for (int i = 0; K1_WAVES * i < n; i++) {
-            const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
-            if (a >= n || !((vm >> a) & 1ull)) continue;
-            const float2 ha = hyp[a * K1_PX + p];
-            const float sa = sgm[a * K1_PX + p];
-            // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
-            unsigned c = (sa * sa > 0.0f) ? 1u : 0u;
-            for (int bb = a + 1; bb < n; bb++) {
-                const float2 hb = hyp[bb * K1_PX + p];
-                if (chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) {
-                    c++;
-                    atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
-                }
-            }
-            atomicAdd(&cnt[(a >> 2) * K1_PX + p], c << (8 * (a & 3)));
+    const bool go = nh > prm.lambdaN;  // PM.cc:221
+    // Branch-and-bound on "the first largest compatible set" (PM.cc:616, strict '>'): a set holds at most the nh
+    // accepted hypotheses, so when the FIRST hypothesis a0 is compatible with all the others its set (size nh) is
+    // the first largest one and no other row needs testing -- nh-1 tests instead of nh(nh-1)/2.  The waves share
+    // row a0's tests (b = w, w+4, ...); pixels it does not settle take the full pair loop below.
+    const int a0 = (int)__ffsll((long long)vm) - 1;  // first accepted hypothesis (-1 if none)
+    bool self0 = false;
+    if (go) {
+        const float2 ha = hyp[a0 * K1_PX + p];
+        const float sa = sgm[a0 * K1_PX + p];
+        self0 = sa * sa > 0.0f;  // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
+        unsigned c = 0;
+        for (int bb = w; bb < n; bb += K1_WAVES) {
+            const float2 hb = hyp[bb * K1_PX + p];  // "no hypothesis" rows hold rho = +Inf: never compatible
+            if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) c++;
         }
+        if (c) atomicAdd(&cnt0[p], c);
     }
     __syncthreads();
+    const bool settled = go && self0 && (int)cnt0[p] + 1 == nh;
+    // lanes are pixels in every wave, so this is the same value in all four waves: a uniform branch around the pair loop
+    const bool any_open = __builtin_amdgcn_ballot_w64(go && !settled) != 0ull;
+    if (any_open) {
+        if (go && !settled) {
+            for (int i = 0; K1_WAVES * i < n; i++) {
+                const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
+                if (a >= n || !((vm >> a) & 1ull)) continue;
+                const float2 ha = hyp[a * K1_PX + p];
+                const float sa = sgm[a * K1_PX + p];
+                // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
+                unsigned c = (sa * sa > 0.0f) ? 1u : 0u;
+                for (int bb = a + 1; bb < n; bb++) {
+                    const float2 hb = hyp[bb * K1_PX + p];
+                    if (chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) {
+                        c++;
+                        atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
+                    }
+                }
+                atomicAdd(&cnt[(a >> 2) * K1_PX + p], c << (8 * (a & 3)));
+            }
+        }
+        __syncthreads();
+    }
 
     unsigned long long n_fused = 0;
     if (w == 0 && on) {
         float2 result = make_float2(0.f, 0.f);  // a fresh depth_map_/depth_sigma_ entry (not fused)
-        if (nh > prm.lambdaN) {
+        if (settled) {
+            // the first hypothesis' set is every accepted hypothesis: GetFusion overload B over them, in order, PM.cc:947-970
+            float pjsj = 0.f, rsj = 0.f;
+            for (int bb = 0; bb < n; bb++) {
+                if (!((vm >> bb) & 1ull)) continue;
+                fusion_accum(hyp[bb * K1_PX + p].x, sgm[bb * K1_PX + p], pjsj, rsj);
+            }
+            result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
+            n_fused = 1;
+        } else if (go) {
             unsigned best = 0;
             int besta = 0;
             for (int a = 0; a < n; a++) {
@@ -509,12 +544,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                 const float2 ha = hyp[besta * K1_PX + p];
                 const float sa = sgm[besta * K1_PX + p];
                 float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
-#if SDM_ABLATE == 8
-                pjsj = ha.x; rsj = ha.y;
-                for (int bb = 0; bb < 0; bb++) {
-#else
                 for (int bb = 0; bb < n; bb++) {
-#endif
                     if (!((vm >> bb) & 1ull)) continue;
                     const float2 hb = hyp[bb * K1_PX + p];
                     const bool in = (bb == besta) ? (sa * sa > 0.0f) : chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p]);

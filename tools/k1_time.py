@@ -1,0 +1,42 @@
+"""K1 (k_search_fuse) launch time on the configs[1] workload for an engine build (SDM_LIB_PATH selects the .so):
+kernel experiments / ablation builds.  usage: python tools/k1_time.py [--res 480p --kfs 64 --nbrs 20 --reps 20]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import sdm_pkg  # noqa: E402
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", default="480p")
+ap.add_argument("--kfs", type=int, default=64)
+ap.add_argument("--nbrs", type=int, default=20)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--disparity", type=float, default=2.6)
+ap.add_argument("--check", action="store_true", help="compare K1 maps with the default library's (bit-exact)")
+a = ap.parse_args()
+pkg = sdm_pkg.load()
+wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0)
+eng, pl = wl.eng, wl.pl
+for _ in range(3):
+    eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
+eng.enable_timing(True)
+eng.get_timing(reset=True)
+for _ in range(a.reps):
+    eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
+eng.synchronize()
+t = eng.get_timing()
+ms = t["search_fuse"][0] / t["search_fuse"][1]
+alg = wl.P * (17 + 9 * a.nbrs) * a.kfs
+print("%s K1 %.4f ms  frac %.4f" % (os.environ.get("SDM_LIB_PATH", "default"), ms, alg / (ms * 1e-3) / 1e9 / 8000.0))
+if a.check:
+    import hashlib
+    h = hashlib.sha256()
+    for k in (0, a.kfs // 2, a.kfs - 1):
+        r, s = eng.download_depth(k)
+        h.update(r.tobytes())
+        h.update(s.tobytes())
+    print("maps sha", h.hexdigest()[:16])
