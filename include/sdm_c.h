@@ -87,6 +87,22 @@ int sdm_upload_keyframe(sdm_ctx *ctx, int slot, const uint8_t *im, const float *
  * fastAtan2 phase, population sigma) -- the pre-processing the reference leaves to the caller. */
 int sdm_upload_image(sdm_ctx *ctx, int slot, const uint8_t *im, const float K[4],
                      const float Tcw[12]);
+/* The step before the path: a camera frame as Tracking receives it.  Replaces, on the device,
+ * Tracking::GrabImageMonocular's cvtColor(RGB/BGR/RGBA/BGRA -> GRAY) (src/Tracking.cc:244-257), the
+ * cv::undistort(im, imu, mK, mDistCoef) of src/Tracking.cc:266-271 and the cvtColor(CV_RGB2GRAY) the Modeler applies
+ * to the stored frame (src/Modeler/Modeler.cc:154-155): undistort the colour frame (1/32-pixel fixed-point map,
+ * bilinear, zero border), convert to gray (4899/9617/1868 >> 14), then the gradient pre-pass of sdm_upload_image.
+ * pixels: H*W interleaved pixels of 1, 3 or 4 bytes.  dist = {k1,k2,p1,p2,k3} as in Examples/Monocular/TUM1.yaml
+ * (Camera.k1.. ; src/Tracking.cc:65-75), NULL = the frame is already undistorted.  The fork's Modeler converts
+ * with CV_RGB2GRAY whatever Camera.RGB says: pass SDM_ORDER_RGB to reproduce that, the true order for a correct gray.
+ * OpenCV is absent here: PARITY UNPINNED, the published algorithms restated. */
+#define SDM_ORDER_RGB 0
+#define SDM_ORDER_BGR 1
+#define SDM_ORDER_RGBA 2
+#define SDM_ORDER_BGRA 3
+#define SDM_ORDER_GRAY 4
+int sdm_upload_image_rgb(sdm_ctx *ctx, int slot, const uint8_t *pixels, int order, const float K[4],
+                         const float dist[5], const float Tcw[12]);
 /* same, image already resident in device memory */
 int sdm_upload_image_device(sdm_ctx *ctx, int slot, const void *d_im, const float K[4],
                             const float Tcw[12]);

@@ -72,6 +72,57 @@ float pmo_fast_atan2(float y, float x)
     return a;
 }
 
+/* ---- image ingest: what the fork does to a camera frame before the path sees it ---------------------
+ * src/Tracking.cc:266-271 cv::undistort(im, imu, mK, mDistCoef) on the colour frame, kept 3-channel by
+ * Modeler::AddFrameImage (src/Modeler/Modeler.cc:1496-1514), converted with cvtColor(CV_RGB2GRAY) at its
+ * use (src/Modeler/Modeler.cc:154-155); Tracking's own gray: src/Tracking.cc:244-257.  OpenCV is absent:
+ * cv::undistort (initUndistortRectifyMap in double -> CV_16SC2 1/32-pixel map -> remap INTER_LINEAR in 15-bit
+ * fixed point, BORDER_CONSTANT 0) and RGB2Gray<uchar> (4899/9617/1868 >> 14) restated from memory, with the
+ * source position evaluated directly per pixel (OpenCV accumulates it along the row).  PARITY UNPINNED (N9). */
+static int ingest_gray(int r, int g, int b) { return (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14; }
+
+void pmo_ingest(const uint8_t *src, int W, int H, int channels, int r_idx, int g_idx, int b_idx,
+                const float K[4], const float *dist, uint8_t *gray)
+{
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const int nc = channels == 1 ? 1 : 3;
+    const int idx[3] = {channels == 1 ? 0 : r_idx, channels == 1 ? 0 : g_idx, channels == 1 ? 0 : b_idx};
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            const int i = v * W + u;
+            if (!dist) {
+                const uint8_t *px = src + (size_t)i * channels;
+                gray[i] = (uint8_t)(channels == 1 ? px[0] : ingest_gray(px[r_idx], px[g_idx], px[b_idx]));
+                continue;
+            }
+            const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+            const double x = ((double)u - cx) / fx, y = ((double)v - cy) / fy;
+            const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+            const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+            const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+            const double us = fx * xd + cx, vs = fy * yd + cy;
+            double fu = rint(us * 32.0), fv = rint(vs * 32.0); /* saturate_cast<int>: round half to even */
+            if (!(fu > -2147483648.0)) fu = -2147483648.0;
+            if (!(fv > -2147483648.0)) fv = -2147483648.0;
+            if (fu > 2147483647.0) fu = 2147483647.0;
+            if (fv > 2147483647.0) fv = 2147483647.0;
+            const int iu = (int)fu, iv = (int)fv;
+            const int sx = iu >> 5, sy = iv >> 5, a = iu & 31, b = iv & 31;
+            const int wt[4] = {(32 - a) * (32 - b) * 32, a * (32 - b) * 32, (32 - a) * b * 32, a * b * 32};
+            int acc[3] = {0, 0, 0};
+            for (int t = 0; t < 4; t++) {
+                const int yy = sy + (t >> 1), xx = sx + (t & 1);
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue; /* BORDER_CONSTANT 0 */
+                const uint8_t *px = src + ((size_t)yy * W + xx) * channels;
+                for (int c = 0; c < nc; c++) acc[c] += wt[t] * (int)px[idx[c]];
+            }
+            int val[3] = {0, 0, 0};
+            for (int c = 0; c < nc; c++) val[c] = (acc[c] + (1 << 14)) >> 15;
+            gray[i] = (uint8_t)(channels == 1 ? val[0] : ingest_gray(val[0], val[1], val[2]));
+        }
+}
+
 /* ---- input pre-pass (not in the reference; SURVEY.md App. B/D defines it for the build) ---- */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

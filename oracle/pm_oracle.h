@@ -73,6 +73,11 @@ void pmo_default_params(pmo_params *p);
 /* cv::fastAtan2 restated from OpenCV 3.x -- PM.cc:414. */
 float pmo_fast_atan2(float y, float x);
 
+/* Image ingest (src/Tracking.cc:244-257, 266-271; src/Modeler/Modeler.cc:154-155): undistort the interleaved
+ * 1/3/4-channel frame (dist = {k1,k2,p1,p2,k3} or NULL) and convert to gray.  OpenCV absent: parity unpinned. */
+void pmo_ingest(const uint8_t *src, int W, int H, int channels, int r_idx, int g_idx, int b_idx,
+                const float K[4], const float *dist, uint8_t *gray);
+
 /* Input pre-pass the reference omits: Scharr/32, magnitude, phase, sigma_I. */
 void pmo_gradient_prepass(const uint8_t *im, int W, int H, float *grad, float *theta,
                           float *I_stddev);

@@ -95,6 +95,7 @@ class Oracle:
                                       C.POINTER(f32p), C.POINTER(f32p), C.c_int, C.POINTER(ParamsC)]
         L.pmo_pointset.argtypes = [C.POINTER(KeyFrameC), f32p, f32p]
         L.pmo_num_threads.restype = C.c_int
+        L.pmo_ingest.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p]
         ip = C.POINTER(C.c_int)
         L.pmo_recon_batch.argtypes = [C.POINTER(KeyFrameC), ip, C.c_int, ip, C.c_int, C.c_float, C.c_float,
                                       C.POINTER(ParamsC), f32p, f32p, C.POINTER(StatsC)]
@@ -142,6 +143,21 @@ class Oracle:
 
     def fast_atan2(self, y, x):
         return float(self.lib.pmo_fast_atan2(float(y), float(x)))
+
+    def ingest(self, pixels, order, K, dist):
+        """camera frame -> undistorted gray (Tracking.cc:244-271, Modeler.cc:154-155); order in rgb/bgr/rgba/bgra/gray"""
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        ch, r, g, b = dict(rgb=(3, 0, 1, 2), bgr=(3, 2, 1, 0), rgba=(4, 0, 1, 2), bgra=(4, 2, 1, 0), gray=(1, 0, 0, 0))[order]
+        H, W = px.shape[:2]
+        assert px.size == H * W * ch
+        k, kp = self._f32(K)
+        dp = None
+        if dist is not None:
+            d, dp = self._f32(dist)
+        out = np.empty((H, W), np.uint8)
+        u8p = C.POINTER(C.c_uint8)
+        self.lib.pmo_ingest(px.ctypes.data_as(u8p), W, H, ch, r, g, b, kp, dp, out.ctypes.data_as(u8p))
+        return out
 
     def gradient_prepass(self, im):
         im = np.ascontiguousarray(im, dtype=np.uint8)

@@ -55,6 +55,7 @@ SYMBOLS = [
     ("sdm_device_count", C.c_int, []),
     ("sdm_upload_keyframe", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     ("sdm_upload_image", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p]),
+    ("sdm_upload_image_rgb", C.c_int, [_ctx, C.c_int, _u8p, C.c_int, _f32p, _f32p, _f32p]),
     ("sdm_upload_image_device", C.c_int, [_ctx, C.c_int, C.c_void_p, _f32p, _f32p]),
     ("sdm_set_pose", C.c_int, [_ctx, C.c_int, _f32p]),
     ("sdm_download_inputs", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p, _f32p]),
@@ -219,6 +220,21 @@ class Engine:
         k, kp = _f32(K)
         T, Tp = _f32(np.asarray(Tcw).reshape(12))
         self._check(self.lib.sdm_upload_image(self.ctx, slot, im.ctypes.data_as(_u8p), kp, Tp))
+
+    ORDER = dict(rgb=0, bgr=1, rgba=2, bgra=3, gray=4)
+
+    def upload_image_rgb(self, slot, pixels, order, K, dist, Tcw):
+        """camera frame [H, W, C] (or [H, W] gray); dist = (k1, k2, p1, p2, k3) or None"""
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        ch = {0: 3, 1: 3, 2: 4, 3: 4, 4: 1}[self.ORDER[order]]
+        assert px.size == self.H * self.W * ch, (px.shape, ch)
+        k, kp = _f32(K)
+        T, Tp = _f32(np.asarray(Tcw).reshape(12))
+        dp = None
+        if dist is not None:
+            d, dp = _f32(dist)
+            assert len(d) == 5
+        self._check(self.lib.sdm_upload_image_rgb(self.ctx, slot, px.ctypes.data_as(_u8p), self.ORDER[order], kp, dp, Tp))
 
     def upload_image_device(self, slot, dev_ptr, K, Tcw):
         k, kp = _f32(K)

@@ -76,6 +76,7 @@ struct sdm_ctx {
     bool stage_busy[2] = {false, false};
     int stage_next = 0;
     uint8_t* d_im = nullptr;
+    uint8_t *d_rgb = nullptr, *h_rgb = nullptr;  // 4P-byte staging for colour frames (sdm_upload_image_rgb), lazily
     float* d_grad = nullptr;
     float* d_theta = nullptr;
     unsigned long long* d_sums = nullptr;
@@ -612,6 +613,8 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_act_count);
     (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
+    (void)hipFree(c->d_rgb);
+    (void)hipHostFree(c->h_rgb);
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
     (void)hipFree(c->d_sums);
@@ -711,6 +714,45 @@ int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], 
     HIP_TRY(hipMemcpyAsync(c->d_im, c->h_im_stage[b], (size_t)c->P, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->stage_done[b], c->stream));
     c->stage_busy[b] = true;
+    KfMeta& m = c->h_meta[slot];
+    fill_meta(m, K, Tcw);
+    m.uploaded = 1;
+    if ((rc = push_meta(c, slot, true))) return rc;
+    return prepass_and_pack(c, slot, c->d_im);
+}
+
+// Tracking.cc:244-257 + 266-271 and Modeler.cc:154-155 on the device: colour order, lens undistortion, gray conversion,
+// then the same pre-pass as sdm_upload_image.
+int sdm_upload_image_rgb(sdm_ctx* c, int slot, const uint8_t* pixels, int order, const float K[4], const float dist[5],
+                         const float Tcw[12])
+{
+    int rc = check_slot(c, slot, false);
+    if (rc) return rc;
+    if (!pixels || !K || !Tcw) return fail(SDM_EINVAL, "null input");
+    IngestParams q{};
+    switch (order) {
+        case SDM_ORDER_RGB: q.channels = 3; q.r_idx = 0; q.g_idx = 1; q.b_idx = 2; break;
+        case SDM_ORDER_BGR: q.channels = 3; q.r_idx = 2; q.g_idx = 1; q.b_idx = 0; break;
+        case SDM_ORDER_RGBA: q.channels = 4; q.r_idx = 0; q.g_idx = 1; q.b_idx = 2; break;
+        case SDM_ORDER_BGRA: q.channels = 4; q.r_idx = 2; q.g_idx = 1; q.b_idx = 0; break;
+        case SDM_ORDER_GRAY: q.channels = 1; break;
+        default: return fail(SDM_EINVAL, "unknown colour order");
+    }
+    q.fx = K[0]; q.fy = K[1]; q.cx = K[2]; q.cy = K[3];
+    q.undistort = dist != nullptr;
+    if (dist) { q.k1 = dist[0]; q.k2 = dist[1]; q.p1 = dist[2]; q.p2 = dist[3]; q.k3 = dist[4]; }
+    if (dist && !(K[0] != 0.0f && K[1] != 0.0f)) return fail(SDM_EINVAL, "zero focal length");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->d_rgb) {
+        if ((rc = dev_alloc(&c->d_rgb, (size_t)c->P * 4)) || (rc = host_alloc(&c->h_rgb, (size_t)c->P * 4))) return rc;
+    }
+    if ((rc = reset_slot(c, slot))) return rc;
+    const size_t bytes = (size_t)c->P * q.channels;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // one pinned colour buffer: the previous frame must have left it
+    memcpy(c->h_rgb, pixels, bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_rgb, c->h_rgb, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ingest, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->d_rgb, c->W, c->H, q, c->d_im);
+    HIP_TRY(hipGetLastError());
     KfMeta& m = c->h_meta[slot];
     fill_meta(m, K, Tcw);
     m.uploaded = 1;

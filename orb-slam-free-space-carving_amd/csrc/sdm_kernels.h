@@ -85,6 +85,72 @@ __device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], uns
 constexpr int HALO_W_K0 = TILE_W + 2;
 constexpr int HALO_H_K0 = TILE_H + 2;
 
+// ---- K(-1): image ingest -- what the fork does to a camera frame before the path sees it --------------------
+// src/Tracking.cc:266-271 undistorts the (colour) frame with cv::undistort(im, imu, mK, mDistCoef) and hands it to
+// Modeler::AddFrameImage, which keeps it 3-channel (src/Modeler/Modeler.cc:1496-1514); the Modeler converts it to
+// gray with cvtColor(CV_RGB2GRAY) where it uses it (src/Modeler/Modeler.cc:154-155); Tracking's own gray image
+// (for ORB) comes from cvtColor(RGB/BGR/RGBA/BGRA -> GRAY), src/Tracking.cc:244-257.
+// One thread per OUTPUT pixel, as cv::undistort does it: the distorted source position in double
+// (initUndistortRectifyMap with R = I and the same camera matrix), rounded to the 1/32-pixel fixed-point map
+// (CV_16SC2 + CV_16UC1, INTER_BITS = 5), bilinear remap in 15-bit fixed point with a constant zero border, then
+// the 8-bit RGB->gray fixed-point weights 4899/9617/1868 >> 14.  OpenCV is absent from the image: this is the
+// published algorithm restated from memory -- PARITY UNPINNED; the oracle states the same
+// arithmetic and the two agree bit for bit.
+struct IngestParams {
+    double fx, fy, cx, cy;
+    double k1, k2, p1, p2, k3;
+    int undistort;  // 0: dist == NULL (copy / grey-convert only)
+    int channels;   // 1, 3 or 4 interleaved bytes per pixel
+    int r_idx, g_idx, b_idx;  // byte index of R, G, B inside a pixel
+};
+
+__device__ __forceinline__ int ingest_gray(int r, int g, int b)
+{
+    return (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;  // RGB2Gray<uchar>: R2Y, G2Y, B2Y, yuv_shift = 14
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ingest(const uint8_t* __restrict__ src, int W, int H, IngestParams q,
+                                                  uint8_t* __restrict__ gray)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= W * H) return;
+    const int v = i / W, u = i - v * W;
+    const int ch = q.channels;
+    if (!q.undistort) {
+        const uint8_t* px = src + (size_t)i * ch;
+        gray[i] = (uint8_t)(ch == 1 ? px[0] : ingest_gray(px[q.r_idx], px[q.g_idx], px[q.b_idx]));
+        return;
+    }
+    const double x = ((double)u - q.cx) / q.fx, y = ((double)v - q.cy) / q.fy;
+    const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+    const double kr = 1 + ((q.k3 * r2 + q.k2) * r2 + q.k1) * r2;
+    const double xd = x * kr + q.p1 * _2xy + q.p2 * (r2 + 2 * x2);
+    const double yd = y * kr + q.p1 * (r2 + 2 * y2) + q.p2 * _2xy;
+    const double us = q.fx * xd + q.cx, vs = q.fy * yd + q.cy;
+    // saturate_cast<int>(double) = round half to even, clamped; a NaN position lands outside the image
+    double fu = rint(us * 32.0), fv = rint(vs * 32.0);
+    if (!(fu > -2147483648.0)) fu = -2147483648.0;
+    if (!(fv > -2147483648.0)) fv = -2147483648.0;
+    if (fu > 2147483647.0) fu = 2147483647.0;
+    if (fv > 2147483647.0) fv = 2147483647.0;
+    const int iu = (int)fu, iv = (int)fv;
+    const int sx = iu >> 5, sy = iv >> 5, a = iu & 31, b = iv & 31;
+    const int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
+    int acc[3] = {0, 0, 0};
+    const int idx[3] = {ch == 1 ? 0 : q.r_idx, ch == 1 ? 0 : q.g_idx, ch == 1 ? 0 : q.b_idx};
+    const int nc = ch == 1 ? 1 : 3;
+    for (int t = 0; t < 4; t++) {
+        const int yy = sy + (t >> 1), xx = sx + (t & 1);
+        const int w = t == 0 ? w00 : (t == 1 ? w01 : (t == 2 ? w10 : w11));
+        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;  // BORDER_CONSTANT, value 0
+        const uint8_t* px = src + ((size_t)yy * W + xx) * ch;
+        for (int c = 0; c < nc; c++) acc[c] += w * (int)px[idx[c]];
+    }
+    int val[3];
+    for (int c = 0; c < nc; c++) val[c] = (acc[c] + (1 << 14)) >> 15;  // FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS>
+    gray[i] = (uint8_t)(ch == 1 ? val[0] : ingest_gray(val[0], val[1], val[2]));
+}
+
 // ---- K0: input pre-pass ---------------------------------------------------------------------------
 // Scharr/32 gradient, magnitude, fastAtan2 phase (the pre-processing PM.cc assumes on KeyFrame:
 // GradImg / GradTheta) + exact integer sums for I_stddev.
