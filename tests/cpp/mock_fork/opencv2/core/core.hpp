@@ -63,6 +63,11 @@ private:
     int type_ = 0;
     std::shared_ptr<std::vector<unsigned char>> buf_;
 };
+struct Point3f {
+    float x, y, z;
+    Point3f() : x(0), y(0), z(0) {}
+    Point3f(float a, float b, float c) : x(a), y(b), z(c) {}
+};
 struct KeyPoint {
     float angle = -1.f;
 };
