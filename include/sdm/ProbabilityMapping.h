@@ -22,6 +22,8 @@
 #include <cstdint>
 #include <iosfwd>
 #include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 /* PM.h:38-49.  covisN is a runtime value here (sdm::Options::covisN, default 7). */
@@ -81,13 +83,29 @@ public:
 class Map {
 public:
     std::vector<KeyFrame*> keyframes;
-    std::vector<KeyFrame*> GetAllKeyFrames() const { return keyframes; }  /* include/Map.h:58 */
+    /* include/Map.h:58 / src/Map.cc:81-85: a copy taken under the map's mutex, so that a mapping thread
+     * (ProbabilityMapping::Run) can poll while another thread inserts keyframes with AddKeyFrame */
+    std::vector<KeyFrame*> GetAllKeyFrames() const
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return keyframes;
+    }
+    void AddKeyFrame(KeyFrame* kf) /* src/Map.cc:38-44 */
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        keyframes.push_back(kf);
+    }
+
+private:
+    mutable std::mutex mutex_;
 };
 
 struct Options {
     int device = 0;
     int covisN = SDM_COVISN_DEFAULT; /* PM.h:38 */
     int max_keyframes = 64;          /* device slots; least-recently-used keyframes are evicted */
+    std::string obj_path = "semi_pointcloud.obj"; /* written when Run() ends, PM.cc:100 */
+    unsigned poll_us = 5000;         /* Run()'s usleep, PM.cc:87 */
 };
 
 }  // namespace sdm
@@ -105,6 +123,15 @@ public:
     explicit ProbabilityMapping(sdm::Map* pMap, const sdm::Options& opt = sdm::Options()); /* PM.h:72 */
     ~ProbabilityMapping();
 
+    /* PM.cc:65-135: the mapping thread's loop -- poll the map, reconstruct every keyframe that is ready
+     * (SemiDenseLoop), re-project after pose changes (UpdateAllSemiDensePointSet), sleep 5 ms; on RequestFinish
+     * write semi_pointcloud.obj and return.  The context is single-caller: while Run() is active no other thread
+     * may call into this object except RequestFinish / isFinished. */
+    void Run();
+    void SemiDenseLoop();            /* PM.cc:137-315 over every keyframe of the map (the form Run() calls at :76) */
+    void RequestFinish();
+    bool isFinished();
+    long Passes();                   /* completed iterations of Run()'s loop (for callers that wait for the map to drain) */
     void SemiDenseRecon(sdm::KeyFrame* kf);                                               /* PM.h:75 */
     void StereoSearchConstraints(sdm::KeyFrame* kf, float* min_depth, float* max_depth);  /* PM.h:77 */
     void EpipolarSearch(sdm::KeyFrame* kf1, sdm::KeyFrame* kf2, const int x, const int y, float pixel,
@@ -165,6 +192,10 @@ private:
     void PushDepth(sdm::KeyFrame* kf, int slot);
     std::vector<sdm::KeyFrame*> PickNeighbours(sdm::KeyFrame* kf);  /* PM.cc:151-160 */
 
+    bool CheckFinish();
+    std::mutex mutex_finish_;
+    bool finish_requested_ = false, finished_ = true;
+    long passes_ = 0;
     sdm::Map* mpMap;
     sdm::Options opt_;
     sdm_ctx* ctx_ = nullptr;

@@ -15,6 +15,8 @@
 #include <iostream>
 #include <string>
 
+#include <unistd.h>
+
 #include "sdm_c.h"
 
 namespace {
@@ -30,6 +32,66 @@ ProbabilityMapping::ProbabilityMapping(sdm::Map* pMap, const sdm::Options& opt) 
 ProbabilityMapping::~ProbabilityMapping()
 {
     if (ctx_) sdm_destroy(ctx_);
+}
+
+// PM.cc:65-135
+void ProbabilityMapping::Run()
+{
+    {
+        std::lock_guard<std::mutex> lock(mutex_finish_);
+        finished_ = false;
+    }
+    while (1) {
+        if (CheckFinish()) break;      // PM.cc:69
+        SemiDenseLoop();               // PM.cc:76
+        UpdateAllSemiDensePointSet();  // PM.cc:79-80: make point positions follow the keyframe poses
+        {
+            std::lock_guard<std::mutex> lock(mutex_finish_);
+            passes_++;
+        }
+        usleep(opt_.poll_us);          // PM.cc:87
+    }
+    if (!opt_.obj_path.empty()) SavePointCloudObj(opt_.obj_path.c_str());  // PM.cc:100-132
+    std::lock_guard<std::mutex> lock(mutex_finish_);
+    finished_ = true;  // PM.cc:134
+}
+
+// the whole-map form of the loop (PM.cc:137-315 before its half-finished refactor to a per-keyframe call): every
+// keyframe that is good, mapped and not reconstructed yet, in map order; SemiDenseRecon also runs the inter-keyframe
+// phase (PM.cc:262-315) for every keyframe that became ready
+void ProbabilityMapping::SemiDenseLoop()
+{
+    if (!mpMap) return;
+    std::vector<sdm::KeyFrame*> vpKFs = mpMap->GetAllKeyFrames();
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        sdm::KeyFrame* kf = vpKFs[i];
+        if (kf->isBad() || kf->semidense_flag_ || !kf->Mapped()) continue;
+        SemiDenseRecon(kf);
+    }
+}
+
+void ProbabilityMapping::RequestFinish()
+{
+    std::lock_guard<std::mutex> lock(mutex_finish_);
+    finish_requested_ = true;
+}
+
+bool ProbabilityMapping::CheckFinish()
+{
+    std::lock_guard<std::mutex> lock(mutex_finish_);
+    return finish_requested_;
+}
+
+long ProbabilityMapping::Passes()
+{
+    std::lock_guard<std::mutex> lock(mutex_finish_);
+    return passes_;
+}
+
+bool ProbabilityMapping::isFinished()
+{
+    std::lock_guard<std::mutex> lock(mutex_finish_);
+    return finished_;
 }
 
 bool ProbabilityMapping::Ensure(int W, int H)

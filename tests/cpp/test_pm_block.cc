@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "sdm/ProbabilityMapping.h"
 
@@ -71,8 +74,40 @@ int main(int argc, char** argv)
     pm.UpdateSemiDensePointSet(&kfs[2]);  // keyframe uploaded again into a fresh slot
     int same = (xyz1 == kfs[1].SemiDensePointSets_.data) && (xyz2 == kfs[2].SemiDensePointSets_.data);
 
+    // ---- the mapping thread (PM.cc:65-135): a second mapper polls a map that fills while it runs -----------------
+    std::vector<sdm::KeyFrame> kt(n_kf);
+    sdm::Map tmap;
+    for (int k = 0; k < n_kf; k++) {
+        kt[k].mnId = k;
+        kt[k].im_ = kfs[k].im_;
+        kt[k].fx = kfs[k].fx; kt[k].fy = kfs[k].fy; kt[k].cx = kfs[k].cx; kt[k].cy = kfs[k].cy;
+        memcpy(kt[k].Tcw, kfs[k].Tcw, sizeof(float) * 12);
+        kt[k].point_depths = kfs[k].point_depths;
+        for (int j : covis[k]) kt[k].covisible.push_back(&kt[j]);
+        tmap.AddKeyFrame(&kt[k]);
+    }
+    sdm::Options topt = opt;
+    topt.obj_path = argc > 3 ? argv[3] : "";
+    topt.poll_us = 1000;
+    ProbabilityMapping pt(&tmap, topt);
+    std::thread th(&ProbabilityMapping::Run, &pt);
+    // the thread owns the keyframes while it runs (the reference reads KeyFrame flags across threads without
+    // synchronisation; this test does not): wait for two full passes (a mutex-guarded counter), then ask it to stop.
+    // Every pass after the first finds nothing left to do, so the result does not depend on the timing.
+    for (int waited = 0; waited < 30000 && pt.Passes() < 2; waited++) usleep(1000);  // two full passes, <= 30 s
+    if (pt.Passes() < 2) return 5;
+    pt.RequestFinish();
+    th.join();
+    int thread_ok = pt.isFinished() ? 1 : 0;
+
     FILE* o = fopen(argv[2], "wb");
     if (!o) return 2;
+    for (int k = 0; k < n_kf; k++) {
+        int flags[3] = {kt[k].semidense_flag_ && thread_ok, kt[k].interKF_depth_flag_, 0};
+        fwrite(flags, sizeof(int), 3, o);
+        fwrite(kt[k].depth_map_.ptr(), sizeof(float), (size_t)W * H, o);
+        fwrite(kt[k].depth_sigma_.ptr(), sizeof(float), (size_t)W * H, o);
+    }
     for (int k = 0; k < n_kf; k++) {
         int flags[3] = {kfs[k].semidense_flag_, kfs[k].interKF_depth_flag_, same};
         fwrite(flags, sizeof(int), 3, o);

@@ -25,6 +25,28 @@ def build_driver(pkg, name="test_pm_class"):
     return exe
 
 
+def oracle_schedule(oracle, seq, n_kf, n, depths):
+    """the reference's driver order on the oracle: SemiDenseRecon per keyframe in map order, each followed by the
+    in-place inter-keyframe check of every keyframe whose neighbours are all reconstructed (PM.cc:137-315)"""
+    W, H = seq.W, seq.H
+    nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
+    bounds = {k: oracle.stereo_search_constraints(depths[k]) for k in range(n_kf)}
+    rho, sig, xyz = {}, {}, {k: np.zeros((H, 3 * W), np.float32) for k in range(n_kf)}
+    semi, inter = [False] * n_kf, [False] * n_kf
+    for k in range(n_kf):
+        mn, mx = bounds[k]
+        rho[k], sig[k], _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, mn, mx)
+        semi[k] = True
+        for i in range(n_kf):  # PM.cc:262-315
+            if inter[i] or not semi[i] or not all(semi[j] for j in nbrs[i]):
+                continue
+            rho[i] = oracle.inter_check(seq.okf[i], rho[i], [seq.okf[j] for j in nbrs[i]],
+                                        [rho[j] for j in nbrs[i]], [sig[j] for j in nbrs[i]])
+            xyz[i] = oracle.pointset(seq.okf[i], rho[i])
+            inter[i] = True
+    return nbrs, bounds, rho, sig, xyz, semi, inter
+
+
 @pytest.mark.parametrize("n_kf,n,max_kf", [(10, 7, 0), (14, 4, 6)])
 def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path, n_kf, n, max_kf):
     """max_kf > 0: fewer device slots than keyframes, so keyframes are evicted (LRU) and re-uploaded with their
@@ -52,21 +74,7 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path, n_kf, 
     subprocess.check_call([exe, str(blob), str(out), str(obj), str(tr)], env=dict(os.environ, SDM_TEST_MAX_KF=str(max_kf)))
 
     # ---- the same schedule on the oracle ----------------------------------------------------------
-    nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
-    bounds = {k: oracle.stereo_search_constraints(depths[k]) for k in range(n_kf)}
-    rho, sig, xyz = {}, {}, {k: np.zeros((H, 3 * W), np.float32) for k in range(n_kf)}
-    semi, inter = [False] * n_kf, [False] * n_kf
-    for k in range(n_kf):
-        mn, mx = bounds[k]
-        rho[k], sig[k], _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, mn, mx)
-        semi[k] = True
-        for i in range(n_kf):  # PM.cc:262-315
-            if inter[i] or not semi[i] or not all(semi[j] for j in nbrs[i]):
-                continue
-            rho[i] = oracle.inter_check(seq.okf[i], rho[i], [seq.okf[j] for j in nbrs[i]],
-                                        [rho[j] for j in nbrs[i]], [sig[j] for j in nbrs[i]])
-            xyz[i] = oracle.pointset(seq.okf[i], rho[i])
-            inter[i] = True
+    nbrs, bounds, rho, sig, xyz, semi, inter = oracle_schedule(oracle, seq, n_kf, n, depths)
     # pose change of keyframe 4 -> re-projected point set (UpdateAllSemiDensePointSet)
     kf4 = oracle.keyframe(seq.im[4], seq.grad[4], seq.theta[4], seq.istd[4], seq.K, seq.Tcw[5])
     if inter[4]:
@@ -167,7 +175,8 @@ def test_cpp_class_block_driver_matches_oracle_snapshot(pkg, oracle, gpu_ok, tmp
     depths = [(1.0 + 0.1 * rng.standard_normal(200)).astype(np.float32) for _ in range(n_kf)]
     blob, out = tmp_path / "in.bin", tmp_path / "out.bin"
     write_blob(blob, seq, n_kf, n, depths)
-    subprocess.check_call([exe, str(blob), str(out)])
+    obj = tmp_path / "thread_cloud.obj"
+    subprocess.check_call([exe, str(blob), str(out), str(obj)])
     nbrs = {k: seq.scene.neighbours(k, n_kf, n_kf - 1)[:n] for k in range(n_kf)}
     rho, sig = {}, {}
     for k in range(n_kf):
@@ -175,6 +184,18 @@ def test_cpp_class_block_driver_matches_oracle_snapshot(pkg, oracle, gpu_ok, tmp
         rho[k], sig[k], _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, mn, mx)
     raw = np.fromfile(out, dtype=np.uint8)
     off, kept = 0, 0
+    # first section: ProbabilityMapping::Run() on its own thread == the reference's sequential driver order
+    _, _, t_rho, t_sig, _, t_semi, t_inter = oracle_schedule(oracle, seq, n_kf, n, depths)
+    for k in range(n_kf):
+        flags = raw[off:off + 12].view(np.int32)
+        off += 12
+        assert bool(flags[0]) == t_semi[k] and bool(flags[1]) == t_inter[k], (k, flags)
+        assert_bit_equal(raw[off:off + 4 * W * H].view(np.float32).reshape(H, W), t_rho[k], "Run(): depth_map_ kf %d" % k)
+        off += 4 * W * H
+        assert_bit_equal(raw[off:off + 4 * W * H].view(np.float32).reshape(H, W), t_sig[k], "Run(): depth_sigma_ kf %d" % k)
+        off += 4 * W * H
+    nv = sum(int(((t_sig[k] <= 0.01) & (t_rho[k] > 1e-6)).sum()) for k in range(n_kf) if t_inter[k])
+    assert sum(1 for line in open(obj) if line.startswith("v ")) == nv  # semi_pointcloud.obj written when Run() ends
     for k in range(n_kf):
         flags = raw[off:off + 12].view(np.int32)
         off += 12

@@ -725,3 +725,60 @@ def test_table_cache_alternating_calls(pkg, oracle, gpu_ok, seq_mid):
                 assert_bit_equal(g[1], w[1], "it %d checked kf %d" % (it, k))
                 assert_bit_equal(g[2], w[2], "it %d xyz kf %d" % (it, k))
     eng.close()
+
+
+def test_search_fuse_with_outlier_hypotheses(pkg, oracle, gpu_ok, seq_mid):
+    """K1's fusion takes a shortcut when the FIRST accepted hypothesis is compatible with all the others (its set is
+    then the first largest one, PM.cc:616) and falls back to the all-pairs count otherwise.  Neighbours with a wrong
+    pose produce consistent-looking but wrong hypotheses (outliers): placed first, in the middle and last in the
+    neighbour order they exercise the fallback, mixed with pixels that take the shortcut, against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import np_pm
+    seq, n = seq_mid, 7
+    eng = pkg.Engine(seq.W, seq.H, seq.n_kf + 2, max_neighbours=n)
+    seq.upload(eng)
+    # two extra slots: keyframes 2 and 5 again, but with their baseline to the others stretched by 40 % / shrunk by 30 %
+    bad = {}
+    for slot, (k, scale) in zip((seq.n_kf, seq.n_kf + 1), ((2, 1.4), (5, 0.7))):
+        T = seq.Tcw[k].copy()
+        T[:, 3] = T[:, 3] * np.float32(scale)
+        eng.upload_keyframe(slot, seq.im[k], seq.grad[k], seq.theta[k], seq.istd[k], seq.K, T)
+        bad[slot] = oracle.keyframe(seq.im[k], seq.grad[k], seq.theta[k], seq.istd[k], seq.K, T)
+    okf = lambda s: bad[s] if s in bad else seq.okf[s]
+    b0, b1 = seq.n_kf, seq.n_kf + 1
+    cases = {3: [b0, 4, 1, 6, 0, 7, 5],      # an outlier source FIRST: the shortcut must not fire on its pixels
+             4: [3, 6, 1, b0, 7, 0, b1],     # outliers in the middle and last
+             6: [7, 4, 3, 1, 0, 2, 5]}       # clean
+    refs = list(cases)
+    eng.search_fuse(refs, [cases[k] for k in refs], seq.min_depth, seq.max_depth)
+    open_px = 0
+    for k in refs:
+        r, s, st = oracle.recon_search_fuse(seq.okf[k], [okf(j) for j in cases[k]], None, seq.min_depth, seq.max_depth)
+        gr, gs = eng.download_depth(k)
+        assert_bit_equal(gr, r, "rho kf %d" % k)
+        assert_bit_equal(gs, s, "sigma kf %d" % k)
+        assert st["fused"] > 500
+        if k != 6:  # how many pixels really needed the all-pairs path (second restatement, tests/np_pm.py)
+            H, W = seq.H, seq.W
+            ys, xs = np.nonzero(~(seq.grad[k][2:H - 2, 2:W - 2] < 8))
+            ys, xs = ys + 2, xs + 2
+            ref = np_pm.KF(seq.im[k], seq.grad[k], seq.theta[k], seq.istd[k], seq.K, seq.Tcw[k])
+            R = np.zeros((len(xs), n), np.float32)
+            S = np.ones((len(xs), n), np.float32)
+            V = np.zeros((len(xs), n), bool)
+            for j, sl in enumerate(cases[k]):
+                src = 2 if sl == b0 else 5 if sl == b1 else sl
+                nb = np_pm.KF(seq.im[src], seq.grad[src], seq.theta[src], seq.istd[src], seq.K, np.array(okf(sl).Tcw[:]).reshape(3, 4))
+                rr, ss, sup, _ = np_pm.epipolar_search(ref, nb, np_pm.Pair(ref, nb), xs, ys, seq.min_depth, seq.max_depth)
+                with np.errstate(all="ignore"):
+                    ok = sup & ((np.float32(1) / rr) > 0)
+                R[:, j], S[:, j], V[:, j] = np.where(ok, rr, 0), np.where(ok, ss, 1), ok
+            comp = np_pm.chi_matrix(R[:, :, None], R[:, None, :], S[:, :, None], S[:, None, :]) & V[:, :, None] & V[:, None, :]
+            nh = V.sum(1)
+            first = V.argmax(1)
+            full = comp[np.arange(len(xs)), first].sum(1) == nh
+            open_px += int(((nh > 3) & ~full).sum())
+            assert int(((nh > 3) & full).sum()) > 100, "some pixels must take the shortcut as well"
+    assert open_px > 300, "the outlier neighbours must force the all-pairs path on many pixels (%d)" % open_px
+    eng.close()
