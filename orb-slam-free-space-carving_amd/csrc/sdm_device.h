@@ -219,6 +219,25 @@ __device__ __forceinline__ void search_range(float fx, float cx, float rxxp, flo
     if (umax > cols) umax = cols;
 }
 
+// The scan only needs the integer ends ceil(umin), floor(umax) of that range (PM.cc:405).  For operands that are not
+// NaN the swap of PM.cc:900-904 is (min, max) and the four clamps of PM.cc:906-909 are a median with 0 and cols;
+// a -0 that min/max/median may return where the reference keeps +0 (or the other way round) becomes the same
+// integer 0.  A NaN end means "no hypothesis" (N5) and is reported before the medians could swallow it.
+__device__ __forceinline__ bool search_range_int(float fx, float cx, float rxxp, float rzxp, float tx, float tz,
+                                                 float mind, float maxd, int W, int& lo, int& hi)
+{
+    float x_min = rxxp * mind + tx, z_min = rzxp * mind + tz;
+    float x_max = rxxp * maxd + tx, z_max = rzxp * maxd + tz;
+    const float u1 = fx * x_min / z_min + cx;
+    const float u2 = fx * x_max / z_max + cx;
+    const float cols = (float)W;
+    const float umin = __builtin_amdgcn_fmed3f(fminf(u1, u2), 0.0f, cols);
+    const float umax = __builtin_amdgcn_fmed3f(fmaxf(u1, u2), 0.0f, cols);
+    lo = (int)ceilf(umin);
+    hi = (int)floorf(umax);
+    return !__builtin_isunordered(u1, u2);
+}
+
 // ---- the two angle gates of the scan, PM.cc:414-431 -----------------------------------------------------
 // Reference statement (every step in float):
 //   d = theta2 - ref;  if (d >= 360) d -= 360;  if (d < 0) d += 360;  if (d > 180) d = 360 - d;
@@ -344,9 +363,8 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float rxxp = row_dot_xp(pc->R + 0, xp0, xp1);
     float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
     float tx = pc->t[0], tz = pc->t[2];
-    float umin, umax;
-    search_range(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, umin, umax);  // PM.cc:404
-    if (!(umin == umin && umax == umax)) return false;
+    int lo, hi;
+    if (!search_range_int(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
 
     // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
     float th_line = fast_atan2_deg_x1(-ab);
@@ -360,8 +378,6 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float old_err = 1000000.0f;
     float best_pe = 0.f, best_ge = 0.f;
     int best_pixel = 0;
-    int lo = (int)ceilf(umin);
-    int hi = (int)floorf(umax);
     if (hi > W - 1) hi = W - 1;
     const float hlim2 = (float)(H - 2);
     // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged (and its

@@ -6,7 +6,7 @@ tail -c 400 gpurun_out/final/bench.json
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -- python3 bench.py --steps 10 --warmup 2 --cpu-kfs 0 --no-extra > gpurun_out/final/kt.log 2>&1 || echo "kernel trace failed"
 f=$(find gpurun_out/final/kt -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then (head -1 "$f"; grep "sdm::" "$f") > gpurun_out/final/kernel_stats.csv; fi
-python3 tools/kstats.py gpurun_out/final/kt
+python3 tools/kstats.py gpurun_out/final/kt || true
 rm -rf gpurun_out/final/kt
 timeout -k 10 200 python bench.py --kfs 256 --cpu-kfs 4 > gpurun_out/final/bench_480p_256kf_n20.json 2>> gpurun_out/final/bench.err || echo "256kf failed"
 timeout -k 10 200 python bench.py --res 720p --kfs 256 --nbrs 7 --cpu-kfs 3 > gpurun_out/final/bench_720p_256kf_n7.json 2>> gpurun_out/final/bench.err || echo "720p failed"

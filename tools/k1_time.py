@@ -15,6 +15,7 @@ ap.add_argument("--res", default="480p")
 ap.add_argument("--kfs", type=int, default=64)
 ap.add_argument("--nbrs", type=int, default=20)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--disparity", type=float, default=2.6)
 ap.add_argument("--check", action="store_true", help="compare K1 maps with the default library's (bit-exact)")
 a = ap.parse_args()
@@ -24,14 +25,19 @@ eng, pl = wl.eng, wl.pl
 for _ in range(3):
     eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
 eng.enable_timing(True)
-eng.get_timing(reset=True)
-for _ in range(a.reps):
-    eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
-eng.synchronize()
-t = eng.get_timing()
-ms = t["search_fuse"][0] / t["search_fuse"][1]
+rounds = []
+for _ in range(a.rounds):  # per-round means: the minimum / median over rounds is robust against clock drift
+    eng.get_timing(reset=True)
+    for _ in range(a.reps):
+        eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
+    eng.synchronize()
+    t = eng.get_timing()
+    rounds.append(t["search_fuse"][0] / t["search_fuse"][1])
+rounds.sort()
+ms = rounds[len(rounds) // 2]
 alg = wl.P * (17 + 9 * a.nbrs) * a.kfs
-print("%s K1 %.4f ms  frac %.4f" % (os.environ.get("SDM_LIB_PATH", "default"), ms, alg / (ms * 1e-3) / 1e9 / 8000.0))
+print("%s K1 median %.4f ms (min %.4f, max %.4f over %d rounds x %d)  frac %.4f" % (
+    os.environ.get("SDM_LIB_PATH", "default"), ms, rounds[0], rounds[-1], a.rounds, a.reps, alg / (ms * 1e-3) / 1e9 / 8000.0))
 if a.check:
     import hashlib
     h = hashlib.sha256()
