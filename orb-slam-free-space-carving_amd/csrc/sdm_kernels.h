@@ -558,7 +558,11 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         if (c) atomicAdd(&cnt0[p], c);
     }
     __syncthreads();
+#if SDM_ABLATE == 9  // diagnostic build: never take the shortcut (every fusing pixel runs the all-pairs count)
+    const bool settled = false;
+#else
     const bool settled = go && self0 && (int)cnt0[p] + 1 == nh;
+#endif
     // lanes are pixels in every wave, so this is the same value in all four waves: a uniform branch around the pair loop
     const bool any_open = __builtin_amdgcn_ballot_w64(go && !settled) != 0ull;
     if (any_open) {
