@@ -316,9 +316,31 @@ def main():
     n_total = wl.n_total * (world if args.independent else 1)
     arch = eng.arch()
     exchanging = world > 1 and not args.independent
+    transport_note = None
     if exchanging and transport == "native":
-        pkg.shard.setup_native_comm(eng)  # the engine's own RCCL communicator (include/sdm_c.h sdm_comm_init)
-        rccl_world = eng.comm_info()[0]
+        # the engine's own RCCL communicator (include/sdm_c.h sdm_comm_init) and one exchange of each form as a
+        # self-check.  If any rank fails (library, communicator or transfer error) ALL ranks agree -- over the
+        # torch.distributed group -- to fall back to the torch transport, and the JSON line says so.
+        ok, why = 1, ""
+        try:
+            pkg.shard.setup_native_comm(eng)
+            wl.step("halo", "native")
+            wl.step("allgather", "native")
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- reported, never swallowed
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            rccl_world = eng.comm_info()[0]
+        else:
+            transport = "torch"
+            transport_note = "native RCCL exchange failed on at least one rank (%s): fell back to torch.distributed" % (
+                why or "another rank")
+            try:
+                eng.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
 
     # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as
     # HOST gray images through sdm_upload_image (H2D copy + device pre-pass + record packing)
@@ -396,6 +418,8 @@ def main():
     }
     if exchange_ms:
         out["exchange_ms_per_step"] = exchange_ms
+    if transport_note:
+        out["transport_note"] = transport_note
     if rehearse:
         out["rehearsal"] = "all ranks on GPU 0, gloo, host-staged exchange: control-flow dry run, not a measurement"
     if stats:

@@ -18,10 +18,33 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--disparity", type=float, default=2.6)
 ap.add_argument("--check", action="store_true", help="compare K1 maps with the default library's (bit-exact)")
+ap.add_argument("--outliers", type=int, default=0,
+                help="replace this many of every keyframe's neighbours by a copy with a wrong pose (baseline stretched by "
+                     "40 %%): their hypotheses are outliers, so no pixel is settled by the fusion shortcut")
 a = ap.parse_args()
 pkg = sdm_pkg.load()
 wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0)
 eng, pl = wl.eng, wl.pl
+if a.outliers:
+    # a second engine with kfs extra slots holding wrong-pose copies; neighbour j of keyframe k at list position
+    # 3, 7, 11, ... is redirected to the copy of j
+    import numpy as np
+    eng.close()
+    n_slots = pl["n_slots"]
+    eng = pkg.Engine(wl.W, wl.H, 2 * n_slots, max_neighbours=a.nbrs, batch_capacity=64)
+    for k in pl["inputs"]:
+        im, _ = wl.scene.render(k, device="cuda")
+        torch.cuda.synchronize()
+        eng.upload_image_device(pl["slot"][k], im.data_ptr(), wl.K, wl.scene.Tcw(k))
+        T = wl.scene.Tcw(k).copy()
+        T[:, 3] *= np.float32(1.4)
+        eng.upload_image_device(n_slots + pl["slot"][k], im.data_ptr(), wl.K, T)
+    nb = [list(r) for r in pl["nbr_slots"]]
+    for r in nb:
+        for i in range(a.outliers):
+            pos = min(3 + 4 * i, len(r) - 1)
+            r[pos] = n_slots + r[pos]
+    pl = dict(pl, nbr_slots=nb)
 for _ in range(3):
     eng.search_fuse(pl["own_slots"], pl["nbr_slots"], wl.min_d, wl.max_d)
 eng.enable_timing(True)
