@@ -100,6 +100,16 @@ private:
     mutable std::mutex mutex_;
 };
 
+/* What one rank does in a sharded pass (ProbabilityMapping::PlanBlock): keyframes are indices into the map's list. */
+struct BlockPlan {
+    std::vector<int> refs;                /* own keyframes reconstructed in this pass (good, not yet semidense, covisN neighbours) */
+    std::vector<std::vector<int> > nbrs;  /* their neighbours, PM.cc:151-160 order */
+    std::vector<char> needed;             /* [all]: images this rank must hold = own block + the refs' neighbours */
+    std::vector<char> boundary;           /* [all]: own keyframes some other rank's check reads: reconstruct first */
+    std::vector<int> send_peer, send_kf;  /* maps that leave: (rank, keyframe), ascending per peer */
+    std::vector<int> recv_peer, recv_kf;  /* maps that arrive; the k-th send to a peer is that peer's k-th receive */
+};
+
 struct Options {
     int device = 0;
     int covisN = SDM_COVISN_DEFAULT; /* PM.h:38 */
@@ -184,6 +194,10 @@ public:
      * SemiDenseRecon left them, the order that shards) -> UpdateSemiDensePointSet.  Collective:
      * every rank calls it once per pass with its own block. */
     bool InitSharding(const unsigned char* comm_id, int world, int rank);
+    /* the plan of a sharded pass, derived identically on every rank from the replicated covisibility lists (host only,
+     * no device work: unit-tested on CPU against shard.plan, tests/test_adapter.py) */
+    static bool PlanBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count, int world, int rank, int covisN,
+                          sdm::BlockPlan* out);
     void SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count);
 
 private:
@@ -191,6 +205,7 @@ private:
     bool Ensure(int W, int H);
     void PushDepth(sdm::KeyFrame* kf, int slot);
     std::vector<sdm::KeyFrame*> PickNeighbours(sdm::KeyFrame* kf);  /* PM.cc:151-160 */
+    static std::vector<sdm::KeyFrame*> PickNeighboursN(sdm::KeyFrame* kf, int covisN);
 
     bool CheckFinish();
     std::mutex mutex_finish_;

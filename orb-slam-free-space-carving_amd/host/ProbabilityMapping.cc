@@ -202,12 +202,14 @@ void ProbabilityMapping::PushDepth(sdm::KeyFrame* kf, int slot)
 }
 
 // PM.cc:151-160 / 273-282: the first covisN covisible keyframes that are good and mapped
-std::vector<sdm::KeyFrame*> ProbabilityMapping::PickNeighbours(sdm::KeyFrame* kf)
+std::vector<sdm::KeyFrame*> ProbabilityMapping::PickNeighbours(sdm::KeyFrame* kf) { return PickNeighboursN(kf, opt_.covisN); }
+
+std::vector<sdm::KeyFrame*> ProbabilityMapping::PickNeighboursN(sdm::KeyFrame* kf, int covisN)
 {
     std::vector<sdm::KeyFrame*> out;
     const std::vector<sdm::KeyFrame*>& all = kf->GetVectorCovisibleKeyFrames();
     for (size_t i = 0; i < all.size(); i++) {
-        if ((int)out.size() >= opt_.covisN) break;
+        if ((int)out.size() >= covisN) break;
         if (all[i]->isBad()) continue;
         if (!all[i]->Mapped()) continue;
         out.push_back(all[i]);
@@ -487,6 +489,63 @@ bool ProbabilityMapping::InitSharding(const unsigned char* comm_id, int world, i
     return true;
 }
 
+// What leaves and what arrives in a sharded pass: derived identically on every rank from the replicated covisibility
+// lists (the C++ counterpart of shard.py's plan()).  Blocks are equal and contiguous: owner(i) = i / count.
+bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count, int world, int rank,
+                                   int covisN, sdm::BlockPlan* out)
+{
+    const int n_all = (int)all.size();
+    if (!out || count < 1 || first < 0 || first + count > n_all || world < 1 || rank < 0 || rank >= world) return false;
+    if (world > 1 && (n_all != world * count || first != rank * count)) return false;
+    std::map<sdm::KeyFrame*, int> index;
+    for (int i = 0; i < n_all; i++) index[all[i]] = i;
+    // neighbours of a keyframe as indices; empty = the keyframe is not reconstructed in this pass (PM.cc:141,160)
+    auto nbr_idx = [&](int i) {
+        std::vector<int> r;
+        sdm::KeyFrame* kf = all[i];
+        if (kf->isBad() || kf->semidense_flag_) return r;
+        std::vector<sdm::KeyFrame*> nb = PickNeighboursN(kf, covisN);
+        if ((int)nb.size() < covisN) return r;
+        for (sdm::KeyFrame* p : nb) {
+            auto it = index.find(p);
+            if (it == index.end()) return std::vector<int>();
+            r.push_back(it->second);
+        }
+        return r;
+    };
+    *out = sdm::BlockPlan();
+    out->needed.assign(n_all, 0);
+    out->boundary.assign(n_all, 0);
+    for (int i = first; i < first + count; i++) {
+        out->needed[i] = 1;
+        std::vector<int> nb = nbr_idx(i);
+        if (nb.empty()) continue;
+        out->refs.push_back(i);
+        out->nbrs.push_back(nb);
+        for (int j : nb) out->needed[j] = 1;
+    }
+    if (world == 1) return true;
+    for (int q = 0; q < world; q++) {
+        if (q == rank) continue;
+        std::vector<char> wanted(n_all, 0);
+        for (int i = q * count; i < (q + 1) * count; i++)
+            for (int j : nbr_idx(i))
+                if (j >= first && j < first + count) wanted[j] = 1;
+        for (int j = first; j < first + count; j++)
+            if (wanted[j]) {
+                out->send_peer.push_back(q);
+                out->send_kf.push_back(j);
+                out->boundary[j] = 1;
+            }
+    }
+    for (int j = 0; j < n_all; j++)
+        if (out->needed[j] && !(j >= first && j < first + count)) {
+            out->recv_peer.push_back(j / count);
+            out->recv_kf.push_back(j);
+        }
+    return true;
+}
+
 void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count)
 {
     const int n_all = (int)all.size();
@@ -497,39 +556,15 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
     if (!Ensure(all[first]->im_.cols, all[first]->im_.rows)) return;
     int world = 1, rank = 0;
     sdm_comm_info(ctx_, &world, &rank);
-    if (world > 1 && (n_all != world * count || first != rank * count)) {
+    sdm::BlockPlan plan;
+    if (!PlanBlock(all, first, count, world, rank, opt_.covisN, &plan)) {
         std::cerr << "ProbabilityMapping::SemiDenseReconBlock: blocks must be equal and contiguous (rank*count)" << std::endl;
         return;
     }
-    std::map<sdm::KeyFrame*, int> index;
-    for (int i = 0; i < n_all; i++) index[all[i]] = i;
-    auto own = [&](int i) { return i >= first && i < first + count; };
-    // neighbours of a keyframe as global indices; empty = the keyframe is skipped (PM.cc:141,160)
-    auto nbr_idx = [&](int i) {
-        std::vector<int> out;
-        sdm::KeyFrame* kf = all[i];
-        if (kf->isBad()) return out;
-        std::vector<sdm::KeyFrame*> nb = PickNeighbours(kf);
-        if ((int)nb.size() < opt_.covisN) return out;
-        for (sdm::KeyFrame* p : nb) {
-            auto it = index.find(p);
-            if (it == index.end()) return std::vector<int>();
-            out.push_back(it->second);
-        }
-        return out;
-    };
-    // this rank's work list and the keyframes whose images it needs
-    std::vector<int> refs;
-    std::vector<std::vector<int>> nbrs;
-    std::vector<char> needed(n_all, 0);
-    for (int i = first; i < first + count; i++) {
-        needed[i] = 1;
-        std::vector<int> nb = all[i]->semidense_flag_ ? std::vector<int>() : nbr_idx(i);
-        if (nb.empty()) continue;
-        refs.push_back(i);
-        nbrs.push_back(nb);
-        for (int j : nb) needed[j] = 1;
-    }
+    const std::vector<int>& refs = plan.refs;
+    const std::vector<std::vector<int> >& nbrs = plan.nbrs;
+    const std::vector<char>& needed = plan.needed;
+    const std::vector<char>& is_boundary = plan.boundary;
     int n_needed = 0;
     for (int i = 0; i < n_all; i++) n_needed += needed[i];
     if (n_needed > (int)slot_owner_.size()) {
@@ -548,30 +583,9 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         }
         if (sdm_mark_depth_present(ctx_, (int)s.size(), s.data()) != SDM_OK) report("SemiDenseReconBlock");
     }
-    // what leaves and what arrives: derived identically on every rank from the replicated covisibility lists
-    std::vector<int> send_peer, send_slot, recv_peer, recv_slot;
-    std::vector<char> is_boundary(n_all, 0);
-    if (world > 1) {
-        for (int q = 0; q < world; q++) {
-            if (q == rank) continue;
-            std::vector<char> wanted(n_all, 0);
-            for (int i = q * count; i < (q + 1) * count; i++)
-                if (!all[i]->semidense_flag_)
-                    for (int j : nbr_idx(i))
-                        if (own(j)) wanted[j] = 1;
-            for (int j = first; j < first + count; j++)
-                if (wanted[j]) {
-                    send_peer.push_back(q);
-                    send_slot.push_back(slot[j]);
-                    is_boundary[j] = 1;
-                }
-        }
-        for (int j = 0; j < n_all; j++)
-            if (needed[j] && !own(j)) {
-                recv_peer.push_back(j / count);
-                recv_slot.push_back(slot[j]);
-            }
-    }
+    std::vector<int> send_peer = plan.send_peer, recv_peer = plan.recv_peer, send_slot, recv_slot;
+    for (int j : plan.send_kf) send_slot.push_back(slot[j]);
+    for (int j : plan.recv_kf) recv_slot.push_back(slot[j]);
     // per-reference constants: depth prior (PM.cc:184) and median in-plane rotations (PM.cc:170-179)
     const int n = opt_.covisN;
     auto run_recon = [&](bool boundary) {
