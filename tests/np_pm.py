@@ -386,8 +386,8 @@ def hypothesis_fusion(rho, sig, valid):
     nh = valid.sum(axis=1)
     fuse = (nh > LAMBDA_N) & (best >= LAMBDA_N)   # PM.cc:221 and :623
     member = member & fuse[:, None]
-    safe = np.where(member.any(axis=1)[:, None], member, np.eye(1, N, dtype=bool))
-    r, s, _ = fusion_b(rho, np.where(sig == 0, f32(1), sig) if False else sig, safe)
+    safe = np.where(member.any(axis=1)[:, None], member, np.eye(1, N, dtype=bool))  # rows that do not fuse: any member will do
+    r, s, _ = fusion_b(rho, sig, safe)
     return np.where(fuse, r, f32(0)).astype(f32), np.where(fuse, s, f32(0)).astype(f32), fuse
 
 
