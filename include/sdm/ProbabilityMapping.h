@@ -104,8 +104,11 @@ private:
 struct BlockPlan {
     std::vector<int> refs;                /* own keyframes reconstructed in this pass (good, not yet semidense, covisN neighbours) */
     std::vector<std::vector<int> > nbrs;  /* their neighbours, PM.cc:151-160 order */
-    std::vector<char> needed;             /* [all]: images this rank must hold = own block + the refs' neighbours */
+    std::vector<int> check;               /* own keyframes checked in this pass: every neighbour has a map by then (PM.cc:292-298) */
+    std::vector<std::vector<int> > check_nbrs;
+    std::vector<char> needed;             /* [all]: keyframes this rank must hold = own block + the refs' and checks' neighbours */
     std::vector<char> boundary;           /* [all]: own keyframes some other rank's check reads: reconstruct first */
+    std::vector<char> recon_all, check_all; /* [all]: reconstructed / checked in this pass by WHICHEVER rank owns it */
     std::vector<int> send_peer, send_kf;  /* maps that leave: (rank, keyframe), ascending per peer */
     std::vector<int> recv_peer, recv_kf;  /* maps that arrive; the k-th send to a peer is that peer's k-th receive */
 };

@@ -29,6 +29,7 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
 };
@@ -56,6 +57,7 @@ int load_rccl()
     SDM_RCCL_SYM(Send, "ncclSend");
     SDM_RCCL_SYM(Recv, "ncclRecv");
     SDM_RCCL_SYM(AllGather, "ncclAllGather");
+    SDM_RCCL_SYM(AllReduce, "ncclAllReduce");
     SDM_RCCL_SYM(CommCount, "ncclCommCount");
     SDM_RCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef SDM_RCCL_SYM
@@ -83,6 +85,10 @@ int comm_streams(sdm_ctx* c)
 
 void comm_release(sdm_ctx* c)
 {
+    // nothing of this context may still be running on the communicator when it is destroyed: the exchange stream and
+    // the compute stream (the all-gather forms run on it; hipStreamSynchronize(nullptr) covers a caller's null stream)
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->own_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
     c->own_comm = false;
@@ -99,7 +105,11 @@ void comm_release(sdm_ctx* c)
     (void)hipFree(c->gather_buf);
     c->gather_buf = nullptr;
     c->gather_slots = 0;
+    (void)hipFree(c->d_agree);
+    c->d_agree = nullptr;
     c->xchg_pending = false;
+    c->ag_open = false;
+    c->ag_pieces.clear();
 }
 
 int check_xchg_slots(sdm_ctx* c, int n, const int* peer, const int* slot, const char* what)
@@ -109,6 +119,19 @@ int check_xchg_slots(sdm_ctx* c, int n, const int* peer, const int* slot, const 
         if (slot[i] < 0 || slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, std::string(what) + " slot out of range");
         if (peer[i] < 0 || peer[i] >= c->world || peer[i] == c->rank)
             return fail(SDM_EINVAL, std::string(what) + " peer out of range (or self)");
+    }
+    return SDM_OK;
+}
+
+// a slot may be received into once, and never while it is also being sent (the transfers of one group are unordered)
+int check_xchg_overlap(sdm_ctx* c, int n_send, const int* send_slot, int n_recv, const int* recv_slot)
+{
+    std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
+    for (int i = 0; i < n_send; i++) seen[send_slot[i]] = 1;  // one map may go to several peers
+    for (int i = 0; i < n_recv; i++) {
+        if (seen[recv_slot[i]] == 1) return fail(SDM_EINVAL, "slot listed both as send and recv");
+        if (seen[recv_slot[i]] == 2) return fail(SDM_EINVAL, "duplicate recv slot");
+        seen[recv_slot[i]] = 2;
     }
     return SDM_OK;
 }
@@ -199,6 +222,7 @@ int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const 
     int rc;
     if ((rc = check_xchg_slots(c, n_send, send_peer, send_slot, "send"))) return rc;
     if ((rc = check_xchg_slots(c, n_recv, recv_peer, recv_slot, "recv"))) return rc;
+    if ((rc = check_xchg_overlap(c, n_send, send_slot, n_recv, recv_slot))) return rc;
     for (int i = 0; i < n_send; i++)
         if (!c->has_depth[send_slot[i]]) return fail(SDM_ESTATE, "send slot has no reconstructed depth map");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -206,15 +230,23 @@ int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const 
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
     const size_t count = (size_t)c->P * 2;  // floats per map {rho,sigma}
     ncclComm_t comm = (ncclComm_t)c->comm;
-    // one group: all sends and receives of this rank progress together (no ordering deadlock between peers)
+    // one group: all sends and receives of this rank progress together (no ordering deadlock between peers).  A
+    // failing call must not leave the thread's group open (every later RCCL call of the thread, torch's included,
+    // would be queued into it and never launched): remember the first failure, close the group, then report it.
     RCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < n_send; i++)
-        RCCL_TRY(g_rccl.Send(c->pool + (long long)send_slot[i] * c->P, count, ncclFloat, send_peer[i], comm,
-                             c->comm_stream));
-    for (int i = 0; i < n_recv; i++)
-        RCCL_TRY(g_rccl.Recv(c->pool + (long long)recv_slot[i] * c->P, count, ncclFloat, recv_peer[i], comm,
-                             c->comm_stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    for (int i = 0; i < n_send && first == ncclSuccess; i++) {
+        first = g_rccl.Send(c->pool + (long long)send_slot[i] * c->P, count, ncclFloat, send_peer[i], comm, c->comm_stream);
+        what = "ncclSend";
+    }
+    for (int i = 0; i < n_recv && first == ncclSuccess; i++) {
+        first = g_rccl.Recv(c->pool + (long long)recv_slot[i] * c->P, count, ncclFloat, recv_peer[i], comm, c->comm_stream);
+        what = "ncclRecv";
+    }
+    const ncclResult_t ended = g_rccl.GroupEnd();
+    if (first != ncclSuccess) return fail(SDM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(first));
+    if (ended != ncclSuccess) return fail(SDM_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ended));
     HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
     for (int i = 0; i < n_recv; i++) {
         c->has_depth[recv_slot[i]] = 1;                    // a peer's finished map (semidense_flag_, PM.cc:294)
@@ -263,6 +295,13 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
         if (dst_slot[i] >= first_slot && dst_slot[i] < first_slot + count)
             return fail(SDM_EINVAL, "fetch would overwrite this rank's own block");
     }
+    if (n_fetch > 0) {
+        std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
+        for (int i = 0; i < n_fetch; i++) {
+            if (seen[dst_slot[i]]) return fail(SDM_EINVAL, "duplicate fetch slot");
+            seen[dst_slot[i]] = 1;
+        }
+    }
     if (n_fetch < 0 && (total > c->cfg.max_keyframes || first_slot != c->rank * count))
         return fail(SDM_EINVAL, "in-place all-gather needs slot == global keyframe index");
     for (int r = 0; r < count; r++)
@@ -296,6 +335,123 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
         c->has_depth[dst_slot[i]] = 1;
         c->recon_lambdaG[dst_slot[i]] = std::nanf("");
     }
+    return SDM_OK;
+}
+
+// ---- all-gather in pieces, overlapped with the reconstruction ------------------------------------------------------
+// The block's keyframes are reconstructed in a few sub-blocks; as soon as one is finished its maps are gathered on the
+// exchange stream (behind an event) while the next sub-block's K1-K3 run on the compute stream -- the same two-event
+// scheme as the halo form.  Piece i = `count` maps from block position `offset` on lands in the gather buffer at
+// [piece base][rank][count]; _finish makes the compute stream wait for the last piece and copies the maps this rank's
+// K4 reads (fetch_index = owner_rank * block_count + position, as for sdm_allgather_depth) into their local slots.
+// With world == 1 the "gather" of a piece is a device copy on the exchange stream, so that the piece bookkeeping and
+// the fetch addressing run (and are tested) on one GPU, too.
+int sdm_allgather_begin(sdm_ctx* c, int first_slot, int block_count)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (c->ag_open) return fail(SDM_ESTATE, "an all-gather is already open: call sdm_allgather_finish first");
+    if (c->xchg_pending) return fail(SDM_ESTATE, "an exchange is in flight: call sdm_exchange_wait first");
+    if (block_count < 1 || first_slot < 0 || first_slot + block_count > c->cfg.max_keyframes)
+        return fail(SDM_EINVAL, "block out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc = comm_streams(c);
+    if (rc) return rc;
+    const long long total = (long long)c->world * block_count;
+    if (c->gather_slots < total) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // earlier fetch copies may still read the old buffer
+        HIP_TRY(hipStreamSynchronize(c->comm_stream));
+        (void)hipFree(c->gather_buf);
+        c->gather_buf = nullptr;
+        c->gather_slots = 0;
+        HIP_TRY(hipMalloc((void**)&c->gather_buf, sizeof(float2) * (size_t)c->P * (size_t)total));
+        c->gather_slots = total;
+    }
+    // the previous pass's fetch copies (compute stream) must have left the buffer before new pieces land in it
+    HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
+    c->ag_open = true;
+    c->ag_first = first_slot;
+    c->ag_count = block_count;
+    c->ag_covered = 0;
+    c->ag_pieces.clear();
+    return SDM_OK;
+}
+
+int sdm_allgather_piece(sdm_ctx* c, int offset, int count)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (!c->ag_open) return fail(SDM_ESTATE, "sdm_allgather_begin first");
+    if (count < 1 || offset != c->ag_covered || offset + count > c->ag_count)
+        return fail(SDM_EINVAL, "pieces must cover the block in order, without gaps or overlap");
+    for (int r = 0; r < count; r++)
+        if (!c->has_depth[c->ag_first + offset + r]) return fail(SDM_ESTATE, "piece slot has no reconstructed depth map");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));  // this piece's K1-K3 are queued on the compute stream
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
+    const size_t piece_floats = (size_t)count * (size_t)c->P * 2;
+    float2* dst = c->gather_buf + (long long)c->world * offset * c->P;  // pieces before this one hold world*offset maps
+    const float2* src = c->pool + (long long)(c->ag_first + offset) * c->P;
+    if (c->world == 1) {
+        HIP_TRY(hipMemcpyAsync(dst, src, piece_floats * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
+    } else {
+        RCCL_TRY(g_rccl.AllGather(src, dst, piece_floats, ncclFloat, (ncclComm_t)c->comm, c->comm_stream));
+    }
+    c->ag_pieces.push_back({offset, count});
+    c->ag_covered = offset + count;
+    return SDM_OK;
+}
+
+int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const int* dst_slot)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (!c->ag_open) return fail(SDM_ESTATE, "sdm_allgather_begin first");
+    if (c->ag_covered != c->ag_count) return fail(SDM_ESTATE, "the pieces do not cover the block yet");
+    if (n_fetch < 0 || (n_fetch > 0 && (!fetch_index || !dst_slot))) return fail(SDM_EINVAL, "bad fetch list");
+    const long long total = (long long)c->world * c->ag_count;
+    std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
+    for (int i = 0; i < n_fetch; i++) {
+        if (fetch_index[i] < 0 || fetch_index[i] >= total) return fail(SDM_EINVAL, "fetch index out of range");
+        if (dst_slot[i] < 0 || dst_slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "fetch slot out of range");
+        if (dst_slot[i] >= c->ag_first && dst_slot[i] < c->ag_first + c->ag_count)
+            return fail(SDM_EINVAL, "fetch would overwrite this rank's own block");
+        if (seen[dst_slot[i]]) return fail(SDM_EINVAL, "duplicate fetch slot");
+        seen[dst_slot[i]] = 1;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
+    for (int i = 0; i < n_fetch; i++) {
+        const int owner = fetch_index[i] / c->ag_count, pos = fetch_index[i] - owner * c->ag_count;
+        const float2* src = nullptr;
+        for (const auto& pc : c->ag_pieces)
+            if (pos >= pc.offset && pos < pc.offset + pc.count)
+                src = c->gather_buf + ((long long)c->world * pc.offset + (long long)owner * pc.count + (pos - pc.offset)) * c->P;
+        HIP_TRY(hipMemcpyAsync(c->pool + (long long)dst_slot[i] * c->P, src, sizeof(float2) * c->P, hipMemcpyDeviceToDevice,
+                               c->stream));
+        c->has_depth[dst_slot[i]] = 1;
+        c->recon_lambdaG[dst_slot[i]] = std::nanf("");
+    }
+    c->ag_open = false;
+    return SDM_OK;
+}
+
+// Go / no-go across the ranks before a collective pass: every rank contributes its local verdict, all receive the
+// minimum.  A rank that cannot take part in the exchange it planned (a keyframe without an image, a failed upload)
+// says so HERE, so that its peers skip the pass instead of waiting for transfers that never come.  Host-blocking.
+int sdm_comm_all_ok(sdm_ctx* c, int local_ok, int* all_ok)
+{
+    if (!c || !all_ok) return fail(SDM_EINVAL, "null argument");
+    *all_ok = local_ok ? 1 : 0;
+    if (c->world == 1) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->d_agree) HIP_TRY(hipMalloc((void**)&c->d_agree, sizeof(int)));
+    const int v = local_ok ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(c->d_agree, &v, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(g_rccl.AllReduce(c->d_agree, c->d_agree, 1, ncclInt, ncclMin, (ncclComm_t)c->comm, c->stream));
+    int out = 0;
+    HIP_TRY(hipMemcpyAsync(&out, c->d_agree, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *all_ok = out;
     return SDM_OK;
 }
 

@@ -38,7 +38,10 @@ struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of th
     float istd;                 // neighbour's I_stddev, PM.cc:457
     int nbr_slot;
     float nfx, nfy, ncx, ncy;  // neighbour intrinsics, PM.cc:675
-    float pad[4];
+    int clean;                 // every angle the scan's two gates see lies in [0,360]: both keyframes' GradTheta planes
+                               // (checked when the records are packed) and rot in [-360,360] -- the closed-form gates
+                               // then hold for every candidate and the scan drops their per-candidate precondition
+    float pad[3];
 };
 static_assert(sizeof(PairConst) == 128, "PairConst must stay 128 B");
 
@@ -280,6 +283,24 @@ __device__ __forceinline__ bool gate3_fails_fast(float d)
     float x = wrap_neg360(d);
     return (x > 45.0f) & (x < 315.0f);
 }
+// The same two decisions with ONE comparison each (comparisons, min/max and conversions issue at half the rate of
+// add/sub/and on this part, tools/ubench/oprate.hip).
+//   gate 2: x in (80,100) or (260,280)  <=>  ||x-180| - 90| < 10.  x-180 is exact wherever it matters (x >= 64: x and 180
+//           are multiples of ulp(x) >= 2^-17 and |x-180| < 256... representable; below 64 the rounded difference stays
+//           above 116, far from [80,100]), and |x-180| - 90 is exact for |x-180| in [45,180] (Sterbenz).
+//   gate 3: 45 < x < 315 as an unsigned range test on the bit pattern (x is never negative after the wrap when d >= -360;
+//           a negative or NaN x lands above the range: not "fails", like the float comparisons).
+// sdm_selftest(3) compares these forms, too, with the reference statement over every float in [-400,400].
+__device__ __forceinline__ bool gate2_fails_fast1(float d)
+{
+    const float x = wrap_neg360(d);
+    return fabsf(fabsf(x - 180.0f) - 90.0f) < 10.0f;
+}
+__device__ __forceinline__ bool gate3_fails_fast1(float d)
+{
+    const float x = wrap_neg360(d);
+    return (__float_as_uint(x) - 0x42340001u) < (0x439D8000u - 0x42340001u);  // bits in (45.0f, 315.0f)
+}
 
 // ---- matching cost, PM.cc:436:  err = (float)((double)pe2 + (double)ge2 / THETA) ------------------------
 // Fast path: s = pe2 + ge2 * (1/THETA) in double differs from the reference's double sum by at most
@@ -335,6 +356,235 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
     return a;
 }
 
+// ---- build-time switches of the K1 scan (A/B builds; every form is bit-identical, tests/test_gpu_arith.py) ----
+// bit 0  no column clamp on the prefetch addresses (they stay inside the plane, see scan_segment)
+// bit 1  two instantiations of the scan: pairs whose angles are all in [0,360] (PairConst::clean) skip the
+//        per-candidate precondition of the closed-form gates
+// bit 2  one-comparison forms of the two angle gates (gate2_fails_fast1 / gate3_fails_fast1)
+// bit 3  match_cost: the magnitude guard as one unsigned range test on the high word
+// bit 4  lerp weight from v_fract instead of floor + add + sub
+// bit 5  search range: min/max through v_med3 (no canonicalising v_max), clamps on the integers
+// bit 6  the in-plane-rotation wrap of PM.cc:425-426 with integer masks instead of compare + select
+#ifndef SDM_K1_OPT
+#define SDM_K1_OPT 0xff
+#endif
+
+// matching cost, PM.cc:436, with the guard of match_cost() as ONE unsigned comparison: the fast double sum is used
+// when 2^-99 <= s < 2^99 (inside the normal float range; negative, NaN and Inf patterns land outside) and its low 29
+// bits are not within 256 of a float rounding midpoint
+__device__ __forceinline__ float match_cost1(float pe2, float ge2, const DevParams& prm)
+{
+    double s = (double)pe2 + (double)ge2 * prm.inv_theta;
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    const bool risky = (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) | ((hi - 0x39C00000u) >= (0x46200000u - 0x39C00000u));
+    if (__builtin_expect(risky, 0)) s = (double)pe2 + (double)ge2 / prm.theta_var;
+    return (float)s;
+}
+
+// lerp weights of bilinear<T> at integer x (PM.cc:40-59): y0w = (floor(yf)+1) - yf, y1w = 1 - y0w.
+// (floor(yf)+1) - yf = 1 - (yf - floor(yf)) in real arithmetic, yf - floor(yf) is exactly representable (what v_fract
+// returns for yf >= 0), so both statements round the same real number: bit-identical (sdm_selftest(8)).
+__device__ __forceinline__ float lerp_w0(float yf)
+{
+#if SDM_K1_OPT & 0x10
+    return 1.0f - __builtin_amdgcn_fractf(yf);
+#else
+    return (floorf(yf) + 1.0f) - yf;
+#endif
+}
+__device__ __forceinline__ float rec_lerp_im_w(const float4& r, float y0w)
+{
+    unsigned w = __float_as_uint(r.w);
+    float y1w = 1.0f - y0w;
+    float v0 = (float)(int)(w & 0xffu), v1 = (float)(int)((w >> 8) & 0xffu);
+    return v0 * y0w + v1 * y1w;
+}
+__device__ __forceinline__ float rec_lerp_grad_w(const float4& r, float y0w)
+{
+    float y1w = 1.0f - y0w;
+    return r.x * y0w + r.z * y1w;
+}
+
+// search range as integers, with fewer half-rate operations than search_range_int: min/max as v_med3 against -/+Inf
+// (fminf/fmaxf cost a canonicalising v_max each), and the clamps of PM.cc:906-909 moved behind the float->int
+// conversion: ceil/floor and a clamp to integer bounds commute, and v_cvt_i32_f32 saturates (+-Inf ends clamp like
+// the float statement).  hi comes back clamped to W-1 (the scan never visits column W, N3).
+__device__ __forceinline__ int cvt_i32_sat(float x)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));  // saturating, NaN -> 0 (the C cast is undefined out of range)
+    return r;
+}
+__device__ __forceinline__ bool search_range_int1(float fx, float cx, float rxxp, float rzxp, float tx, float tz,
+                                                  float mind, float maxd, int W, int& lo, int& hi)
+{
+    float x_min = rxxp * mind + tx, z_min = rzxp * mind + tz;
+    float x_max = rxxp * maxd + tx, z_max = rzxp * maxd + tz;
+    const float u1 = fx * x_min / z_min + cx;
+    const float u2 = fx * x_max / z_max + cx;
+    const float mn = __builtin_amdgcn_fmed3f(u1, u2, -__builtin_inff());
+    const float mx = __builtin_amdgcn_fmed3f(u1, u2, __builtin_inff());
+    lo = min(max(cvt_i32_sat(ceilf(mn)), 0), W);
+    hi = min(max(cvt_i32_sat(floorf(mx)), 0), W - 1);
+    return !__builtin_isunordered(u1, u2);
+}
+
+// PM.cc:424-426: ang = th_pi + rot;  if (ang >= 360) ang -= 360;  if (ang < 0) ang += 360;
+// Integer-mask form (add / sub / shift / and issue at the full rate, compare + select at half of it):
+//   * a + 0.0f first turns a -0 into +0 (the reference would keep -0; the only consumer is d3 = theta2 - ang, where the
+//     two differ only in the sign of a zero difference, and both signs pass gate 3 under either statement);
+//   * "a >= 360": a non-negative float orders like its bit pattern; the sign mask excludes negative values; a positive
+//     NaN subtracts 360 and stays NaN;
+//   * "a < 0" is then the sign bit (no -0 left), wrap_neg360.
+// sdm_selftest(8) compares it with the reference statement over every float in [-800, 800] and the special values.
+__device__ __forceinline__ float wrap_once_360_ref(float a)
+{
+    if (a >= 360) a -= 360;
+    if (a < 0) a += 360;
+    return a;
+}
+__device__ __forceinline__ float wrap_once_360(float a)
+{
+#if SDM_K1_OPT & 0x40
+    a = a + 0.0f;
+    const unsigned bits = __float_as_uint(a);
+    const unsigned lt360 = (unsigned)((int)(bits - 0x43B40000u) >> 31);  // all ones iff bits < bits(360.0f) (for a >= +0)
+    const unsigned neg = (unsigned)((int)bits >> 31);
+    unsigned keep = lt360 | neg;
+    asm("" : "+v"(keep));  // keeps hipcc from turning the mask back into a compare + select
+    a = a + __uint_as_float(~keep & 0xC3B40000u);  // - 360.0f or + 0.0f
+    return wrap_neg360(a);
+#else
+    return wrap_once_360_ref(a);
+#endif
+}
+
+struct ScanState {
+    float old_err, best_pe, best_ge;
+    int best_pixel;
+};
+
+// PM.cc:405-443: the scan over uj = lo..hi of one search.  Candidates are visited in increasing uj exactly as the
+// reference does (the strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four at a
+// time so that four independent 16-byte gathers are in flight per lane.  Fetch rows are clamped into [1, H-2]
+// (validity is decided separately from the unclamped value); fetch columns run to hi+3 <= W+2 at most, and
+// (H-2)*W + W+2 < H*W, so every address stays inside the neighbour's plane without a column clamp.
+// CLEAN: every angle is in [0,360] (PairConst::clean), so d2, d3 are in [-360,360] and the closed-form gates hold for
+// every candidate; otherwise a candidate with d >= gate_lim (or NaN) takes the reference statement.
+template <bool STATS, bool CLEAN>
+__device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int W, int H, int lo, int hi, float ab,
+                                             float cb, float pixel, float grad1, float th_line, float ang_pi_rot,
+                                             float gate_lim, const DevParams& prm, ScanState& S, SearchStats* st)
+{
+    // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged (and its
+    // integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3 in one comparison
+    const float hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
+    const unsigned W16 = (unsigned)W << 4;  // record pitch in bytes (< 2^24)
+#if !(SDM_K1_OPT & 0x01)
+    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
+#endif
+    float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
+#if SDM_K1_OPT & 0x80
+    // records through a buffer descriptor over the neighbour's plane: the hardware range check returns zeros for any
+    // offset outside it, so the fetch row needs no clamp, and the row test of PM.cc:408 + N3 (1 <= yf < H-1) is an
+    // unsigned range test on the bit pattern of t = -yf (a positive yf orders like its bits; negative, NaN and huge
+    // values land outside) -- one comparison, no v_med3.  The row index of an invalid candidate is garbage; its
+    // record (whatever it is) is never used.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(nbase), (short)0,
+                                                                          (int)((unsigned)W * (unsigned)H * 16u), 0x00020000);
+    const unsigned row_span = __float_as_uint((float)(H - 1)) - 0x3F800000u;  // bits(H-1) - bits(1.0f)
+#endif
+    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
+        float yfs[SCAN_UNROLL];
+        unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
+        v4f rs[SCAN_UNROLL];
+        const unsigned c0 = (unsigned)u0 << 4;
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+#if SDM_K1_OPT & 0x80
+            const float t = ab * (u0f + (float)k) + cb;  // -yf, PM.cc:407,433
+            yfs[k] = -t;
+            rowok[k] = __builtin_amdgcn_uicmp(__float_as_uint(t) - 0xBF800000u, row_span, 36 /* unsigned < */);
+            int row;
+            asm("v_cvt_i32_f32_e64 %0, -%1" : "=v"(row) : "v"(t));  // saturating; the C cast is undefined out of range
+            const unsigned off = __umul24((unsigned)row, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
+#if SDM_ABLATE == 5
+            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
+#else
+            rs[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16 * k, 0));
+#endif
+#else
+            float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
+            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
+#if SDM_K1_OPT & 0x01
+            const unsigned off = __umul24((unsigned)(int)yc, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
+            const char* __restrict__ nb_k = nbase + 16 * k;
+#else
+            unsigned uc16 = min(c0 + 16u * k, hi16);                    // min(uj, hi) * 16
+            unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
+            const char* __restrict__ nb_k = nbase;
+#endif
+            yfs[k] = yf;
+            rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
+#if SDM_ABLATE == 5
+            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
+#else
+            rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
+#endif
+#endif
+        }
+        // keep each record one 16-byte gather issued here: without this hipcc splits the first record
+        // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++)
+            asm volatile("" : "+v"(rs[k]));
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+            const int uj = u0 + k;
+            if (STATS && uj <= hi) st->candidates++;
+            const float yf = yfs[k];
+            const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
+            if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
+            if (r.x < prm.lambdaG) continue;                            // PM.cc:411
+#if SDM_ABLATE == 4
+            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+            continue;
+#endif
+            const float d2 = r.y - th_line;     // PM.cc:415-416
+            const float d3 = r.y - ang_pi_rot;  // PM.cc:427
+#if SDM_K1_OPT & 0x04
+            bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
+#else
+            bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+#endif
+            if (!CLEAN) {
+                if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
+                    fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
+            }
+            if (fail) continue;  // PM.cc:421,431
+            if (STATS) st->gate_pass++;
+#if SDM_ABLATE == 3 || SDM_ABLATE == 4
+            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+            continue;
+#endif
+            const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
+            float pe = pixel - rec_lerp_im_w(r, y0w);          // PM.cc:433
+            float ge = grad1 - rec_lerp_grad_w(r, y0w);        // PM.cc:434
+#if SDM_K1_OPT & 0x08
+            float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
+#else
+            float err = match_cost(pe * pe, ge * ge, prm);
+#endif
+            if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
+                S.best_pixel = uj;
+                S.old_err = err;
+                S.best_pe = pe;
+                S.best_ge = ge;
+            }
+        }
+    }
+}
+
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
 // nrec: the neighbour keyframe's record plane.  Returns true iff a hypothesis was produced
 // (dh.supported).  Normative choices N3-N5 for the reference's undefined behaviour: DESIGN.md §3.
@@ -364,31 +614,23 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
     float tx = pc->t[0], tz = pc->t[2];
     int lo, hi;
+#if SDM_K1_OPT & 0x20
+    if (!search_range_int1(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
+#else
     if (!search_range_int(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
+    if (hi > W - 1) hi = W - 1;
+#endif
 
     // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
     float th_line = fast_atan2_deg_x1(-ab);
-    float ang_pi_rot = th_pi + pc->rot;  // PM.cc:424-426
-    if (ang_pi_rot >= 360) ang_pi_rot -= 360;
-    if (ang_pi_rot < 0) ang_pi_rot += 360;
+    float ang_pi_rot = wrap_once_360(th_pi + pc->rot);  // PM.cc:424-426
 
     // closed-form gates need d < 360 and the default thresholds; with other thresholds the limit is -Inf and
     // every candidate takes the reference statement (a float limit keeps the test free of a uniform-bool VGPR)
     const float gate_lim = prm.default_gates ? 360.0f : -__builtin_inff();
-    float old_err = 1000000.0f;
-    float best_pe = 0.f, best_ge = 0.f;
-    int best_pixel = 0;
-    if (hi > W - 1) hi = W - 1;
+    ScanState S = {1000000.0f, 0.f, 0.f, 0};
     const float hlim2 = (float)(H - 2);
-    // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged (and its
-    // integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3 in one comparison
-    const float hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
     const char* __restrict__ nbase = reinterpret_cast<const char*>(nrec);
-    // PM.cc:405 scan.  Candidates are visited in increasing uj exactly as the reference does (the
-    // strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four
-    // at a time so that four independent 16-byte gathers are in flight per lane.  Fetch addresses
-    // are clamped into the image (32-bit byte offsets from a scalar base); validity is decided
-    // separately from the unclamped values.
 #if SDM_ABLATE == 10
     if (ang_pi_rot + th_line + (float)(hi - lo) != 12345.678f) return false;  // keep the set-up alive, skip the rest
 #endif
@@ -397,71 +639,17 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 #endif
 #if SDM_ABLATE == 6
     hi = lo - 1;
-    old_err = ab;
-    best_pixel = lo + 2;
+    S.old_err = ab;
+    S.best_pixel = lo + 2;
 #endif
-    const unsigned W16 = (unsigned)W << 4;  // record pitch in bytes (< 2^24)
-    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
-    float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
-    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
-        float yfs[SCAN_UNROLL];
-        unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
-        v4f rs[SCAN_UNROLL];
-#pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++) {
-            int uj = u0 + k;
-            float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
-            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
-            unsigned uc16 = min(((unsigned)u0 << 4) + 16u * k, hi16);  // min(uj, hi) * 16
-            unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
-            yfs[k] = yf;
-            rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
-#if SDM_ABLATE == 5
-            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
-#else
-            rs[k] = *reinterpret_cast<const v4f*>(nbase + off);
+#if SDM_K1_OPT & 0x02
+    if (pc->clean && prm.default_gates)  // wave-uniform (the pair's constants sit in scalar registers)
+        scan_segment<STATS, true>(nbase, W, H, lo, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim, prm, S, st);
+    else
 #endif
-        }
-        // keep each record one 16-byte gather issued here: without this hipcc splits the first record
-        // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
-#pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++)
-            asm volatile("" : "+v"(rs[k]));
-#pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++) {
-            const int uj = u0 + k;
-            if (STATS && uj <= hi) st->candidates++;
-            const float yf = yfs[k];
-            const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
-            if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
-            if (r.x < prm.lambdaG) continue;                            // PM.cc:411
-#if SDM_ABLATE == 4
-            if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
-            continue;
-#endif
-            const float d2 = r.y - th_line;     // PM.cc:415-416
-            const float d3 = r.y - ang_pi_rot;  // PM.cc:427
-            bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
-            if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
-                fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
-            if (fail) continue;  // PM.cc:421,431
-            if (STATS) st->gate_pass++;
-#if SDM_ABLATE == 3 || SDM_ABLATE == 4
-            if (r.z > old_err) { best_pixel = uj; old_err = r.z; }
-            continue;
-#endif
-            const float vj1 = floorf(yf) + 1.0f;             // (float)((int)yf + 1): yf is in [1, H-1) here
-            float pe = pixel - rec_lerp_im(r, vj1, yf);    // PM.cc:433
-            float ge = grad1 - rec_lerp_grad(r, vj1, yf);  // PM.cc:434
-            float err = match_cost(pe * pe, ge * ge, prm);  // PM.cc:436
-            if (err < old_err) {  // PM.cc:437 strict: lowest uj wins ties
-                best_pixel = uj;
-                old_err = err;
-                best_pe = pe;
-                best_ge = ge;
-            }
-        }
-    }
+        scan_segment<STATS, false>(nbase, W, H, lo, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim, prm, S, st);
+    const float old_err = S.old_err, best_pe = S.best_pe, best_ge = S.best_ge;
+    const int best_pixel = S.best_pixel;
     if (!(old_err < 1000000.0f)) return false;  // PM.cc:446
 #if SDM_ABLATE == 2
     rho_o = old_err + best_pe + (float)best_pixel;

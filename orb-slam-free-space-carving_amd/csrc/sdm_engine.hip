@@ -62,6 +62,7 @@ struct sdm_ctx {
     std::vector<char> has_depth, has_chk;
     unsigned* d_act = nullptr;     // [max_keyframes][P] active-pixel lists (y<<16|x), raster order
     int* d_act_count = nullptr;    // [max_keyframes]
+    int* d_theta_bad = nullptr;    // [max_keyframes] GradTheta plane holds a value outside [0,360] (k_pack)
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
     bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
@@ -97,7 +98,7 @@ struct sdm_ctx {
         std::vector<int> refs, nbrs;
         std::vector<float> rot, mind, maxd;
     };
-    static constexpr int TABLE_SETS = 4;
+    static constexpr int TABLE_SETS = 8;  // sub-block calls of the pipelined all-gather step + the whole-block K4 call
     struct TableSet {
         unsigned char *d_tab = nullptr, *h_tab = nullptr;
         RefConst* d_refs = nullptr;
@@ -142,6 +143,14 @@ struct sdm_ctx {
     bool xchg_pending = false;
     float2* gather_buf = nullptr;  // [world*count] maps, the not-in-place all-gather's landing zone
     long long gather_slots = 0;
+    // all-gather in pieces (sdm_allgather_begin / _piece / _finish)
+    struct AgPiece {
+        int offset, count;
+    };
+    bool ag_open = false;
+    int ag_first = 0, ag_count = 0, ag_covered = 0;
+    std::vector<AgPiece> ag_pieces;
+    int* d_agree = nullptr;  // sdm_comm_all_ok
 };
 
 namespace {
@@ -341,8 +350,8 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     HIP_TRY(hipMemcpyAsync(c->d_tab, c->h_tab, bytes, hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_pair_setup, dim3(blocks_for((long long)np)), dim3(BLOCK), 0, c->stream, c->d_meta,
-                           c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, n_ref, n,
-                           c->d_refs, c->d_pairs);
+                           c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, c->d_theta_bad,
+                           n_ref, n, c->d_refs, c->d_pairs);
     } else {
         hipLaunchKernelGGL(k_ref_setup, dim3(blocks_for(n_ref)), dim3(BLOCK), 0, c->stream, c->d_meta, c->d_ref_slots,
                            c->d_act_count, n_ref, c->d_refs);
@@ -392,6 +401,7 @@ int reset_slot(sdm_ctx* c, int slot)
     c->xyz_sparse[slot] = 1;
     HIP_TRY(hipMemsetAsync(c->pool + (long long)slot * c->P, 0, sizeof(float2) * c->P, c->stream));
     HIP_TRY(hipMemsetAsync(c->chk + (long long)slot * c->P, 0, sizeof(float) * c->P, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_theta_bad + slot, 0, sizeof(int), c->stream));  // k_pack sets it again if need be
     if (c->xyz) HIP_TRY(hipMemsetAsync(c->xyz + (long long)slot * c->P * 3, 0, sizeof(float) * 3 * c->P, c->stream));
     return SDM_OK;
 }
@@ -408,7 +418,7 @@ void fill_meta(KfMeta& m, const float K[4], const float Tcw[12])
 int pack_staged(sdm_ctx* c, int slot)
 {
     hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->d_im, c->d_grad, c->d_theta,
-                       c->W, c->H, c->rec + (long long)slot * c->P);
+                       c->W, c->H, c->rec + (long long)slot * c->P, c->d_theta_bad + slot);
     HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
@@ -423,7 +433,7 @@ int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
                        c->d_meta + slot);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->d_grad, c->d_theta,
-                       c->W, c->H, c->rec + (long long)slot * c->P);
+                       c->W, c->H, c->rec + (long long)slot * c->P, c->d_theta_bad + slot);
     HIP_TRY(hipGetLastError());
     return build_active(c, slot);
 }
@@ -548,6 +558,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_meta, (size_t)K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_act, (size_t)c->P * K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_act_count, (size_t)K))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_theta_bad, (size_t)K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_chunk, (size_t)((c->P + ACT_BLOCK - 1) / ACT_BLOCK)))) return bail(rc);
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
@@ -580,6 +591,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->chk, 0, sizeof(float) * c->P * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_meta, 0, sizeof(KfMeta) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_act_count, 0, sizeof(int) * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_theta_bad, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -611,6 +623,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_act);
     (void)hipFree(c->d_act_count);
+    (void)hipFree(c->d_theta_bad);
     (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_rgb);
@@ -1379,6 +1392,8 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
         return SDM_OK;
     } else if (which == 6) {
         hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
+    } else if (which == 8) {
+        hipLaunchKernelGGL(k_selftest_scan_ids, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else if (which == 3) {
         hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else {

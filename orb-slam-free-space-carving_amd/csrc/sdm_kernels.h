@@ -241,21 +241,28 @@ __global__ __launch_bounds__(BLOCK) void k_istd_finish(const unsigned long long*
 }
 
 // pack im/grad/theta planes into the 16-byte search records (layout: sdm_device.h)
+// theta_bad: set when any GradTheta value lies outside [0,360] (or is NaN): the slot's pairs then keep the
+// per-candidate precondition of the closed-form angle gates (PairConst::clean).  The device pre-pass (fastAtan2) never
+// produces such a value; a caller's own planes (sdm_upload_keyframe) may.
 __global__ __launch_bounds__(BLOCK) void k_pack(const uint8_t* __restrict__ im, const float* __restrict__ grad,
                                                 const float* __restrict__ theta, int W, int H,
-                                                float4* __restrict__ rec)
+                                                float4* __restrict__ rec, int* __restrict__ theta_bad)
 {
     int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= W * H) return;
-    int y = idx / W;
-    bool below = (y + 1 < H);
-    unsigned bits = (unsigned)im[idx] | ((below ? (unsigned)im[idx + W] : 0u) << 8);
-    float4 r;
-    r.x = grad[idx];
-    r.y = theta[idx];
-    r.z = below ? grad[idx + W] : 0.0f;
-    r.w = __uint_as_float(bits);
-    rec[idx] = r;
+    bool bad = false;
+    if (idx < W * H) {
+        int y = idx / W;
+        bool below = (y + 1 < H);
+        unsigned bits = (unsigned)im[idx] | ((below ? (unsigned)im[idx + W] : 0u) << 8);
+        float4 r;
+        r.x = grad[idx];
+        r.y = theta[idx];
+        r.z = below ? grad[idx + W] : 0.0f;
+        r.w = __uint_as_float(bits);
+        rec[idx] = r;
+        bad = !(r.y >= 0.0f && r.y <= 360.0f);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(theta_bad, 1);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_unpack(const float4* __restrict__ rec, int n, uint8_t* __restrict__ im,
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_unpack(const float4* __restrict__ rec
 __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restrict__ ref_slots,
                              const int* __restrict__ nbr_slots, const float* __restrict__ rot,
                              const float* __restrict__ mind, const float* __restrict__ maxd,
-                             const int* __restrict__ act_counts, int n_ref, int n,
+                             const int* __restrict__ act_counts, const int* __restrict__ theta_bad, int n_ref, int n,
                              RefConst* __restrict__ refs, PairConst* __restrict__ pairs)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +299,10 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     pc.nfy = m2.fy;
     pc.ncx = m2.cx;
     pc.ncy = m2.cy;
-    pc.pad[0] = pc.pad[1] = pc.pad[2] = pc.pad[3] = 0.f;
+    // th_pi, theta2 in [0,360] and rot in [-360,360] => th_pi + rot in [-360,720] => one wrap lands in [0,360] => d2, d3
+    // in [-360,360]: the closed-form gates of the scan hold for every candidate of this pair (sdm_device.h)
+    pc.clean = (theta_bad[ref_slots[r]] == 0 && theta_bad[nbr_slots[idx]] == 0 && pc.rot >= -360.0f && pc.rot <= 360.0f) ? 1 : 0;
+    pc.pad[0] = pc.pad[1] = pc.pad[2] = 0.f;
     pairs[idx] = pc;
     if (j == 0) {
         RefConst rc;
@@ -1444,6 +1454,39 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
     }
 }
 
+// which = 8: two scan identities over EVERY float bit pattern: (a) the lerp weight 1 - fract(yf) vs (floor(yf)+1) - yf for
+// yf >= 0 (the scan and the refinement only form it for rows yf in [0, H-1)); (b) the integer-mask wrap of
+// PM.cc:425-426 vs the compare statement -- values must agree bit for bit except that a -0 result may come back as +0
+// (wrap_once_360's note), NaN matches NaN.  bad = mismatches, aux = operands tested.
+__global__ __launch_bounds__(BLOCK) void k_selftest_scan_ids(unsigned long long* __restrict__ bad,
+                                                             unsigned long long* __restrict__ tested)
+{
+    unsigned long long cnt = 0, n = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float f = __uint_as_float((unsigned)i);
+        if (f >= 0.0f && f < 16777216.0f) {
+            const float a = 1.0f - __builtin_amdgcn_fractf(f), b = (floorf(f) + 1.0f) - f;
+            if (__float_as_uint(a) != __float_as_uint(b)) cnt++;
+            n++;
+        }
+        {
+            const float a = wrap_once_360(f), b = wrap_once_360_ref(f);
+            const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b) || (a == 0.0f && b == 0.0f);
+            if (!same) cnt++;
+            n++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        n += __shfl_down(n, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(bad, cnt);
+        atomicAdd(tested, n);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_selftest_chi(int iters, unsigned long long* __restrict__ bad,
                                                         unsigned long long* __restrict__ inband)
 {
@@ -1511,6 +1554,16 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_cost(DevParams prm, int iter
         }
         float ref = (float)((double)pe2 + (double)ge2 / prm.theta_var);
         float got = match_cost(pe2, ge2, prm);
+        if (!(ref == got || (ref != ref && got != got))) cnt++;
+        got = match_cost1(pe2, ge2, prm);
+        if (!(ref == got || (ref != ref && got != got))) cnt++;
+        // magnitudes around and beyond the guard of both forms (tiny / huge squares)
+        const float sc = exp2f((float)((int)(xs32(s) % 400u) - 200));
+        const float pe2s = pe2 * sc, ge2s = ge2 * sc;
+        ref = (float)((double)pe2s + (double)ge2s / prm.theta_var);
+        got = match_cost1(pe2s, ge2s, prm);
+        if (!(ref == got || (ref != ref && got != got))) cnt++;
+        got = match_cost(pe2s, ge2s, prm);
         if (!(ref == got || (ref != ref && got != got))) cnt++;
         double sfast = (double)pe2 + (double)ge2 * prm.inv_theta;
         unsigned lo = (unsigned)__double2loint(sfast);
@@ -1603,6 +1656,8 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_gates(unsigned long long* __
         if (!(d < 360.0f)) return;  // the kernel's guard routes these to the reference form
         if (gate2_fails_fast(d) != gate2_fails_ref(d, 80.0f)) cnt++;
         if (gate3_fails_fast(d) != gate3_fails_ref(d, 45.0f)) cnt++;
+        if (gate2_fails_fast1(d) != gate2_fails_ref(d, 80.0f)) cnt++;  // the one-comparison forms the scan uses
+        if (gate3_fails_fast1(d) != gate3_fails_ref(d, 45.0f)) cnt++;
         n++;
     };
     // (a) strided sweep of the positive and negative float line up to |d| = 400 (0x43C80000)

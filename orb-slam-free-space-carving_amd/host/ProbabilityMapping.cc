@@ -489,8 +489,15 @@ bool ProbabilityMapping::InitSharding(const unsigned char* comm_id, int world, i
     return true;
 }
 
-// What leaves and what arrives in a sharded pass: derived identically on every rank from the replicated covisibility
-// lists (the C++ counterpart of shard.py's plan()).  Blocks are equal and contiguous: owner(i) = i / count.
+// What one rank does in a sharded pass, derived identically on every rank from REPLICATED state only: the keyframe
+// list, the covisibility lists and the flags bad / mapped / semidense_flag_ / interKF_depth_flag_ (SemiDenseReconBlock
+// keeps the two stage flags replicated: after a pass it sets them on every keyframe that ANY rank reconstructed or
+// checked, see the end of that function).  The C++ counterpart of shard.py's plan().  Blocks are equal and contiguous:
+// owner(i) = i / count.
+//   refs   keyframes reconstructed in this pass (PM.cc:141,160: good, not yet semidense, covisN good+mapped neighbours)
+//   check  keyframes checked in this pass (PM.cc:265-298: good, not yet checked, semidense by the end of this pass's
+//          reconstruction, covisN neighbours that are ALL semidense by then) -- the reference's gate: a keyframe whose
+//          neighbour has no depth map yet is not checked, and nobody sends or receives a map that does not exist
 bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count, int world, int rank,
                                    int covisN, sdm::BlockPlan* out)
 {
@@ -499,12 +506,10 @@ bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int f
     if (world > 1 && (n_all != world * count || first != rank * count)) return false;
     std::map<sdm::KeyFrame*, int> index;
     for (int i = 0; i < n_all; i++) index[all[i]] = i;
-    // neighbours of a keyframe as indices; empty = the keyframe is not reconstructed in this pass (PM.cc:141,160)
+    // PM.cc:151-160 as indices; empty = fewer than covisN usable neighbours (or one outside `all`)
     auto nbr_idx = [&](int i) {
         std::vector<int> r;
-        sdm::KeyFrame* kf = all[i];
-        if (kf->isBad() || kf->semidense_flag_) return r;
-        std::vector<sdm::KeyFrame*> nb = PickNeighboursN(kf, covisN);
+        std::vector<sdm::KeyFrame*> nb = PickNeighboursN(all[i], covisN);
         if ((int)nb.size() < covisN) return r;
         for (sdm::KeyFrame* p : nb) {
             auto it = index.find(p);
@@ -516,21 +521,42 @@ bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int f
     *out = sdm::BlockPlan();
     out->needed.assign(n_all, 0);
     out->boundary.assign(n_all, 0);
+    out->recon_all.assign(n_all, 0);
+    out->check_all.assign(n_all, 0);
+    std::vector<std::vector<int> > nb_all(n_all);
+    for (int i = 0; i < n_all; i++) {
+        if (all[i]->isBad()) continue;
+        nb_all[i] = nbr_idx(i);
+        if (!all[i]->semidense_flag_ && !nb_all[i].empty()) out->recon_all[i] = 1;
+    }
+    auto will_have_map = [&](int j) { return all[j]->semidense_flag_ || out->recon_all[j]; };
+    for (int i = 0; i < n_all; i++) {
+        if (all[i]->isBad() || all[i]->interKF_depth_flag_ || nb_all[i].empty() || !will_have_map(i)) continue;
+        bool ready = true;  // PM.cc:292-298
+        for (int j : nb_all[i]) ready = ready && will_have_map(j);
+        if (ready) out->check_all[i] = 1;
+    }
     for (int i = first; i < first + count; i++) {
         out->needed[i] = 1;
-        std::vector<int> nb = nbr_idx(i);
-        if (nb.empty()) continue;
-        out->refs.push_back(i);
-        out->nbrs.push_back(nb);
-        for (int j : nb) out->needed[j] = 1;
+        if (out->recon_all[i]) {
+            out->refs.push_back(i);
+            out->nbrs.push_back(nb_all[i]);
+            for (int j : nb_all[i]) out->needed[j] = 1;
+        }
+        if (out->check_all[i]) {
+            out->check.push_back(i);
+            out->check_nbrs.push_back(nb_all[i]);
+            for (int j : nb_all[i]) out->needed[j] = 1;
+        }
     }
     if (world == 1) return true;
     for (int q = 0; q < world; q++) {
         if (q == rank) continue;
         std::vector<char> wanted(n_all, 0);
         for (int i = q * count; i < (q + 1) * count; i++)
-            for (int j : nbr_idx(i))
-                if (j >= first && j < first + count) wanted[j] = 1;
+            if (out->check_all[i])
+                for (int j : nb_all[i])
+                    if (j >= first && j < first + count) wanted[j] = 1;
         for (int j = first; j < first + count; j++)
             if (wanted[j]) {
                 out->send_peer.push_back(q);
@@ -538,8 +564,12 @@ bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int f
                 out->boundary[j] = 1;
             }
     }
+    std::vector<char> fetch(n_all, 0);
+    for (const std::vector<int>& row : out->check_nbrs)
+        for (int j : row)
+            if (!(j >= first && j < first + count)) fetch[j] = 1;
     for (int j = 0; j < n_all; j++)
-        if (out->needed[j] && !(j >= first && j < first + count)) {
+        if (fetch[j]) {
             out->recv_peer.push_back(j / count);
             out->recv_kf.push_back(j);
         }
@@ -565,24 +595,44 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
     const std::vector<std::vector<int> >& nbrs = plan.nbrs;
     const std::vector<char>& needed = plan.needed;
     const std::vector<char>& is_boundary = plan.boundary;
+
+    // ---- everything that can fail locally happens BEFORE the first transfer is posted, and the ranks agree on a
+    // go / no-go: a rank that returned early here used to leave its peers waiting for maps that never came
+    bool local_ok = true;
     int n_needed = 0;
     for (int i = 0; i < n_all; i++) n_needed += needed[i];
     if (n_needed > (int)slot_owner_.size()) {
         std::cerr << "ProbabilityMapping::SemiDenseReconBlock: " << n_needed << " keyframes (block + covisible halo) "
                   << "exceed Options::max_keyframes = " << slot_owner_.size() << std::endl;
-        return;
+        local_ok = false;
     }
     std::vector<int> slot(n_all, -1);
-    for (int i = 0; i < n_all; i++)
-        if (needed[i] && (slot[i] = SlotOf(all[i])) < 0) return;
-    {   // own keyframes that are not reconstructed in this pass still answer a peer's request (with the map they have)
+    for (int i = 0; i < n_all && local_ok; i++)
+        if (needed[i] && (slot[i] = SlotOf(all[i])) < 0) local_ok = false;
+    if (local_ok) {
+        // own keyframes reconstructed in an earlier pass answer with the map they have (the host copy, if the device
+        // slot was recycled); a keyframe without a map is never marked: nobody's plan reads it (PlanBlock)
         std::vector<int> s;
-        for (int i = first; i < first + count; i++) {
-            if (all[i]->semidense_flag_) PushDepth(all[i], slot[i]);  // a fresh slot already holds the zero map
-            s.push_back(slot[i]);
+        for (int i = first; i < first + count; i++)
+            if (all[i]->semidense_flag_) {
+                PushDepth(all[i], slot[i]);
+                s.push_back(slot[i]);
+            }
+        if (!s.empty() && sdm_mark_depth_present(ctx_, (int)s.size(), s.data()) != SDM_OK) {
+            report("SemiDenseReconBlock");
+            local_ok = false;
         }
-        if (sdm_mark_depth_present(ctx_, (int)s.size(), s.data()) != SDM_OK) report("SemiDenseReconBlock");
     }
+    int all_ok = 0;
+    if (sdm_comm_all_ok(ctx_, local_ok ? 1 : 0, &all_ok) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        return;
+    }
+    if (!all_ok) {
+        if (local_ok) std::cerr << "ProbabilityMapping::SemiDenseReconBlock: another rank cannot run this pass; skipped" << std::endl;
+        return;
+    }
+
     std::vector<int> send_peer = plan.send_peer, recv_peer = plan.recv_peer, send_slot, recv_slot;
     for (int j : plan.send_kf) send_slot.push_back(slot[j]);
     for (int j : plan.recv_kf) recv_slot.push_back(slot[j]);
@@ -615,39 +665,53 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         }
         return true;
     };
-    if (!run_recon(true)) return;  // the keyframes other ranks read first ...
+    // From here to sdm_exchange_wait this rank takes part in the exchange WHATEVER happens locally: a failed
+    // reconstruction still posts the planned sends (of whatever the slots hold) and receives, and is reported after
+    bool ok = run_recon(true);  // the keyframes other ranks read first ...
+    if (!ok && !send_slot.empty()) (void)sdm_mark_depth_present(ctx_, (int)send_slot.size(), send_slot.data());
     if (sdm_exchange_halo_begin(ctx_, (int)send_peer.size(), send_peer.data(), send_slot.data(), (int)recv_peer.size(),
                                 recv_peer.data(), recv_slot.data()) != SDM_OK) {
-        report("SemiDenseReconBlock");
-        return;
+        report("SemiDenseReconBlock");  // argument / state errors are the same on every rank (replicated plan); an RCCL
+        ok = false;                     // failure is fatal for the communicator anyway
     }
-    if (!run_recon(false)) return;  // ... the rest while those maps travel
+    ok = run_recon(false) && ok;  // ... the rest while those maps travel
     if (sdm_exchange_wait(ctx_) != SDM_OK) {
         report("SemiDenseReconBlock");
-        return;
+        ok = false;
     }
-    if (refs.empty()) return;
-    std::vector<int> r, ns;
-    for (size_t a = 0; a < refs.size(); a++) {
-        r.push_back(slot[refs[a]]);
-        for (int j : nbrs[a]) ns.push_back(slot[j]);
-    }
-    // the maps as SemiDenseRecon left them (PM.cc:244), then PM.cc:300-306 for the whole block, snapshot order
+    if (!ok) return;
+    // the maps as SemiDenseRecon left them (PM.cc:244)
     for (size_t a = 0; a < refs.size(); a++) {
         sdm::KeyFrame* kf = all[refs[a]];
-        if (sdm_download_depth(ctx_, r[a], kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK) report("SemiDenseReconBlock");
+        if (sdm_download_depth(ctx_, slot[refs[a]], kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK) report("SemiDenseReconBlock");
+        depth_on_device_[kf] = 1;
         kf->semidense_flag_ = true;
     }
-    if (sdm_inter_check_pointset(ctx_, (int)r.size(), r.data(), n, ns.data(), /*commit=*/0) != SDM_OK) {
-        report("SemiDenseReconBlock");
-        return;
-    }
-    for (size_t a = 0; a < refs.size(); a++) {
-        sdm::KeyFrame* kf = all[refs[a]];
-        if (sdm_download_checked(ctx_, r[a], kf->depth_map_.ptr()) != SDM_OK ||
-            sdm_download_pointset(ctx_, r[a], kf->SemiDensePointSets_.ptr()) != SDM_OK)
+    // PM.cc:300-306 for every keyframe of the block that is ready, snapshot order
+    if (!plan.check.empty()) {
+        std::vector<int> r, ns;
+        for (size_t a = 0; a < plan.check.size(); a++) {
+            r.push_back(slot[plan.check[a]]);
+            for (int j : plan.check_nbrs[a]) ns.push_back(slot[j]);
+        }
+        if (sdm_inter_check_pointset(ctx_, (int)r.size(), r.data(), n, ns.data(), /*commit=*/0) != SDM_OK) {
             report("SemiDenseReconBlock");
-        depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
-        kf->interKF_depth_flag_ = true;  // PM.cc:306
+            return;
+        }
+        for (size_t a = 0; a < plan.check.size(); a++) {
+            sdm::KeyFrame* kf = all[plan.check[a]];
+            if (sdm_download_checked(ctx_, r[a], kf->depth_map_.ptr()) != SDM_OK ||
+                sdm_download_pointset(ctx_, r[a], kf->SemiDensePointSets_.ptr()) != SDM_OK)
+                report("SemiDenseReconBlock");
+            depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
+            kf->interKF_depth_flag_ = true;  // PM.cc:306
+        }
+    }
+    // keep the stage flags REPLICATED: what the other ranks reconstructed / checked in this pass (their maps live on
+    // their GPUs; this rank's copies of those keyframes carry only the flags).  The next pass's plan is derived from
+    // these flags on every rank, so they must not depend on who did the work.
+    for (int i = 0; i < n_all; i++) {
+        if (plan.recon_all[i]) all[i]->semidense_flag_ = true;
+        if (plan.check_all[i]) all[i]->interKF_depth_flag_ = true;
     }
 }

@@ -193,7 +193,23 @@ def setup_native_comm(eng, group=None):
 _gather_cache = {}
 
 
-def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, transport="torch"):
+def sub_blocks(count, pieces):
+    """(offset, count) of `pieces` nearly equal contiguous sub-blocks of a block of `count` keyframes"""
+    pieces = max(1, min(pieces, count))
+    base, extra = divmod(count, pieces)
+    out, off = [], 0
+    for i in range(pieces):
+        c = base + (1 if i < extra else 0)
+        out.append((off, c))
+        off += c
+    return out
+
+
+AG_PIECES = 4  # sub-blocks of the pipelined all-gather (native transport)
+
+
+def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, transport="torch", ag_pieces=AG_PIECES,
+                  force_pieces=False):
     """One pass of the hot path over this rank's keyframe block (what bench.py times and the
     multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
     check (K4, snapshot form) + point set (K5; back-projected in the checking kernel).
@@ -218,6 +234,14 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, tran
         else:
             wait_all(works)
             eng.mark_depth_present([s for _, s in halo_lists(pl)[1]])
+    elif native and ag_pieces > 1 and (world > 1 or force_pieces):  # force_pieces: the world-1 rehearsal of the tests
+        # all-gather, pipelined: the block is reconstructed in sub-blocks; each one's maps are gathered on the
+        # engine's exchange stream while the next one's K1-K3 run (sdm_allgather_begin / _piece / _finish)
+        eng.allgather_begin(pl["first_slot"], pl["count"])
+        for off, cnt in sub_blocks(pl["count"], ag_pieces):
+            eng.recon(own[off:off + cnt], nbrs[off:off + cnt], min_d, max_d)
+            eng.allgather_piece(off, cnt)
+        eng.allgather_finish(fetch_list(pl))
     else:
         eng.recon(own, nbrs, min_d, max_d)
         if world > 1:

@@ -78,3 +78,13 @@ def test_inter_check_fast_body_vs_reference_statement(pkg, gpu_ok):
     total = 1024 * 256 * 2048
     assert 0.25 * total < accepted <= total, accepted  # the fast path is the common case, and it is really exercised
     eng.close()
+
+
+def test_scan_identities(pkg, gpu_ok):
+    """K1 scan: lerp weight 1 - fract(yf) == (floor(yf)+1) - yf for every float in [0, 2^24); the integer-mask wrap of
+    PM.cc:425-426 == the compare statement for every float bit pattern (up to the sign of a zero)"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, tested = eng.selftest(8)
+    assert bad == 0
+    assert tested > 2 ** 32
+    eng.close()
