@@ -52,11 +52,13 @@ def parse():
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
-    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
-                    help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with "
-                         "(the other form is timed too and reported under exchange_ms_per_step)")
+    ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather"],
+                    help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: the "
+                         "all-gather BASELINE.json names (pipelined in sub-blocks behind the reconstruction), or the halo "
+                         "point-to-point form (the other one is timed too: exchange_ms_per_step, value_<other>)")
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="N>1: RCCL called by the engine's C ABI (sdm_exchange_*) or torch.distributed on the pool tensor")
+    ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (SURVEY.md §8d adversarial set)")
     ap.add_argument("--independent", action="store_true",
                     help="N>1: one independent sequence per GPU, no exchange (BASELINE.json configs[4])")
     return ap.parse_args()
@@ -99,7 +101,7 @@ class Workload:
     """One resident workload on this rank: scene, plan, engine, uploaded keyframes."""
 
     def __init__(self, pkg, torch, res, kfs, N, disparity, world, rank, local_rank, independent=False,
-                 keep_images=0):
+                 keep_images=0, noise=False, outliers=0):
         synth, shard = pkg.synth, pkg.shard
         self.pkg, self.torch = pkg, torch
         cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[res]
@@ -108,17 +110,19 @@ class Workload:
         self.independent = independent
         if independent:  # configs[4]: every GPU has its own sequence (seeds 0x5EED0050..57), no exchange
             self.n_total = kfs
-            self.scene = synth.Scene(cam, 0x5EED0050 + rank, disparity_px=disparity)
+            self.scene = synth.Scene(cam, 0x5EED0050 + rank, disparity_px=disparity, noise_images=noise)
             self.pl = shard.plan(kfs, 1, 0, N, self.scene.neighbours)
         else:
             self.n_total = kfs * world
-            self.scene = synth.Scene(cam, SEEDS[res], disparity_px=disparity)
+            self.scene = synth.Scene(cam, SEEDS[res], disparity_px=disparity, noise_images=noise)
             self.pl = shard.plan(self.n_total, world, rank, N, self.scene.neighbours)
         pl = self.pl
+        self.outliers = outliers
+        n_slots = pl["n_slots"] * (2 if outliers else 1)
         self.min_d, self.max_d = self.scene.depth_prior()
         # engine on torch's current stream; depth pool owned by torch (the torch transport exchanges it in place)
-        self.pool = torch.zeros((pl["n_slots"], self.H, self.W, 2), dtype=torch.float32, device="cuda")
-        self.eng = pkg.Engine(self.W, self.H, pl["n_slots"], max_neighbours=N, device=local_rank,
+        self.pool = torch.zeros((n_slots, self.H, self.W, 2), dtype=torch.float32, device="cuda")
+        self.eng = pkg.Engine(self.W, self.H, n_slots, max_neighbours=N, device=local_rank,
                               batch_capacity=min(kfs, 64), with_pointset=True, ext_depth_pool=self.pool.data_ptr(),
                               stream=torch.cuda.current_stream().cuda_stream)
         self.K = self.scene.K()
@@ -130,9 +134,26 @@ class Workload:
             self.eng.upload_image_device(pl["slot"][k], im.data_ptr(), self.K, self.scene.Tcw(k))
             if k < keep_images:
                 self.images[k] = im.cpu().numpy()
+            if outliers:  # a wrong-pose copy of every keyframe (baseline stretched by 40 %) in the upper half of the slots
+                T = self.scene.Tcw(k).copy()
+                T[:, 3] *= 1.4
+                self.eng.upload_image_device(pl["n_slots"] + pl["slot"][k], im.data_ptr(), self.K, T)
+        if outliers:
+            # `outliers` of every keyframe's neighbours (list positions 3, 7, 11, ...) are redirected to the wrong-pose
+            # copy: their hypotheses are consistent-looking outliers, so the first accepted hypothesis is not compatible
+            # with all others and the fusion's shortcut does not settle the pixel
+            nb = [list(r) for r in pl["nbr_slots"]]
+            for r in nb:
+                for i in range(outliers):
+                    pos = min(3 + 4 * i, len(r) - 1)
+                    r[pos] = pl["n_slots"] + r[pos]
+            self.pl = dict(pl, nbr_slots=nb)
         self.t_gen = time.time() - t0
 
     def step(self, exchange, transport, group=None):
+        if self.outliers:  # K1 only: the wrong-pose copies are neighbours, never reference keyframes (no maps for K4)
+            self.eng.search_fuse(self.pl["own_slots"], self.pl["nbr_slots"], self.min_d, self.max_d)
+            return
         self.pkg.shard.pipeline_step(self.eng, self.pool, self.pl, self.min_d, self.max_d, exchange, group, transport)
 
     def scan_stats(self):
@@ -199,13 +220,15 @@ def roofline(wl, timing, steps, traffic):
     k1_bytes = wl.P * (17 + 9 * wl.N) * len(wl.pl["own"]) * steps / max(k1_n, 1)
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
     out = {
-        "bound": "hbm", "kernel": "k_search_fuse",
+        # what the counters say bounds the kernel (profiles/*_pmc.txt): the vector ALU's issue slots are
+        # ~85 % full while the HBM pins carry ~0.2 of their peak.  achieved / peak / frac stay SURVEY.md §8d's figure:
+        # ALGORITHMIC bytes per launch over the launch time, against the HBM peak.
+        "bound": "valu-issue", "model": "hbm (SURVEY.md §8d algorithmic bytes / HBM peak)", "kernel": "k_search_fuse",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
         "launch_ms": round(k1_avg_ms, 4), "launches": k1_n,
         "algorithmic_bytes_per_launch": k1_bytes,
-        # what the counters say limits the kernel (profiles/): vector-instruction issue, not HBM
         "limiter": "valu-issue",
     }
     if traffic:
@@ -213,6 +236,28 @@ def roofline(wl, timing, steps, traffic):
         out["hbm_frac"] = round(out["hbm_GBs"] / HBM_PEAK_GBS, 4)
         out["traffic_source"] = "profiles/ PMC run (rocprofv3 --pmc, TCC_EA0 request counters) of this build and workload"
     return out, k1_avg_ms
+
+
+def step_roofline(wl, ms_step):
+    """all kernels of the step: SURVEY.md §8d's algorithmic bytes K1 P(17+9N) + K2 16P + K3 20P + K4 P(8+8N) + K5 16P =
+    P(77+17N) per keyframe, over the measured step time, against the HBM peak"""
+    b = wl.P * (77 + 17 * wl.N) * len(wl.pl["own"])
+    gbs = b / (ms_step * 1e-3) / 1e9
+    return {"algorithmic_bytes_per_step": b, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "note": "the dense-plane byte model overstates the list kernels' work: K2-K5 touch only the ~20 % of the "
+                    "pixels the reference touches (PM.cc:201, 662); their own counters are in profiles/"}
+
+
+def measure(wl, steps, warmup, barrier, exchange, transport, reduce_max=None):
+    """the contract's W warm-up + K timed steps twice: straight after set-up (cold clocks: *_cold) and again after the
+    pre-warm phase (steady state: the figures `value` / `roofline` report)"""
+    dt_c, timing_c = timed(wl, steps, warmup, barrier, exchange, transport)
+    n_pre = prewarm(wl, barrier, exchange, transport, reduce_max)
+    dt, timing = timed(wl, steps, warmup, barrier, exchange, transport)
+    if reduce_max is not None:
+        dt_c, dt = reduce_max(dt_c), reduce_max(dt)
+    return dt, timing, dt_c, timing_c, n_pre
 
 
 def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps):
@@ -245,23 +290,35 @@ def scan_record(stats, k1_avg_ms):
     }
 
 
-def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier):
-    """one more single-GPU BASELINE workload, measured the same way as the headline one"""
-    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank)
+def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier, noise=False, outliers=0, tag=None):
+    """one more single-GPU workload, measured the same way as the headline one (cold and steady state)"""
+    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank, noise=noise, outliers=outliers)
     stats = wl.scan_stats()
-    prewarm(wl, barrier, "halo", "torch")
-    dt, timing = timed(wl, steps, warmup, barrier, "halo", "torch")
-    rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps))
+    dt, timing, dt_c, timing_c, _ = measure(wl, steps, warmup, barrier, "halo", "torch")
+    plain = not (noise or outliers)
+    rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps)
+                          if plain else None)
+    rf_c, _ = roofline(wl, timing_c, steps, None)
+    rf["frac_cold"] = rf_c["frac"]
+    rf["launch_ms_cold"] = rf_c["launch_ms"]
+    name = workload_name(wl.W, wl.H, kfs, N, res) if plain and disparity == 2.6 else \
+        "%dx%d, %d keyframes x %d neighbours: %s" % (wl.W, wl.H, kfs, N, tag)
     out = {
-        "workload": workload_name(wl.W, wl.H, kfs, N, res),
+        "workload": name,
         "value": round(wl.P * wl.n_total * steps / dt / 1e6, 2), "unit": "Mpix*KF/s",
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
-        "keyframes_total": wl.n_total, "neighbours": N,
+        "ms_per_step_cold": round(dt_c / steps * 1e3, 4),
+        "keyframes_total": wl.n_total, "neighbours": N, "disparity_px": disparity,
         "stage_ms_per_step": {s: round(v[0] / steps, 4) for s, v in timing.items()},
         "roofline": rf,
         "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
         "scan": scan_record(stats, k1_avg),
     }
+    if outliers:
+        out["stages"] = "K1 only (k_search_fuse): %d of every keyframe's %d neighbours are wrong-pose copies" % (outliers, N)
+        del out["value"], out["unit"]
+    else:
+        out["step_roofline"] = step_roofline(wl, dt / steps * 1e3)
     wl.close()
     return out
 
@@ -310,7 +367,7 @@ def main():
         torch.cuda.synchronize()
 
     wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
-                  independent=args.independent,
+                  independent=args.independent, noise=args.noise,
                   keep_images=(args.cpu_kfs + 2 * args.nbrs) if (rank == 0 and world == 1) else 0)
     eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
     n_total = wl.n_total * (world if args.independent else 1)
@@ -363,10 +420,9 @@ def main():
             return float(tt.item())
         return dt
 
-    n_prewarm = prewarm(wl, barrier, args.exchange, transport, reduce_max if world > 1 else None)
-    dt, timing = timed(wl, args.steps, args.warmup, barrier, args.exchange, transport)
-    dt = reduce_max(dt)
-    exchange_ms = None
+    dt, timing, dt_cold, timing_cold, n_prewarm = measure(wl, args.steps, args.warmup, barrier, args.exchange, transport,
+                                                          reduce_max if world > 1 else None)
+    exchange_ms, other, dt2 = None, None, None
     if exchanging:  # the other exchange form, same K steps, so the line carries both
         other = "allgather" if args.exchange == "halo" else "halo"
         dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
@@ -383,7 +439,10 @@ def main():
     value = P * n_total * args.steps / dt / 1e6
     rf, k1_avg_ms = roofline(wl, timing, args.steps,
                              committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps)
-                             if world == 1 else None)
+                             if (world == 1 and not args.noise) else None)
+    rf_cold, _ = roofline(wl, timing_cold, args.steps, None)
+    rf["frac_cold"] = rf_cold["frac"]  # the same K steps after only the W warm-up steps (no pre-warm phase)
+    rf["launch_ms_cold"] = rf_cold["launch_ms"]
     if not exchanging:
         xdesc = "no exchange (%s)" % ("1 GPU" if world == 1 else "independent sequences")
     else:
@@ -397,13 +456,17 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4),
+        # the same W + K steps run straight after set-up, before the pre-warm phase (clocks / caches not settled)
+        "ms_per_step_cold": round(dt_cold / args.steps * 1e3, 4),
+        "value_cold": round(P * n_total * args.steps / dt_cold / 1e6, 2),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": workload_name(W, H, args.kfs, N, args.res, args.independent),
+            "workload": workload_name(W, H, args.kfs, N, args.res, args.independent) +
+                        (", i.i.d. uniform u8 noise images" if args.noise else ""),
             "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" % xdesc,
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
             "parallelism": ("independent x%d" if args.independent else "keyframe-block x%d") % world, "arch": arch,
@@ -415,9 +478,12 @@ def main():
         },
         "stage_ms_per_step": {s: round(v[0] / args.steps, 4) for s, v in timing.items()},
         "roofline": rf,
+        "step_roofline": step_roofline(wl, ms_step),
     }
     if exchange_ms:
         out["exchange_ms_per_step"] = exchange_ms
+        out["value_" + other] = round(P * n_total * args.steps / dt2 / 1e6, 2)
+        out["config"]["allgather_pieces"] = pkg.shard.AG_PIECES if transport == "native" else 1
     if transport_note:
         out["transport_note"] = transport_note
     if rehearse:
@@ -437,12 +503,22 @@ def main():
     if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs) == ("480p", 64, 20):
         wl.close()
         extra = []
-        for (res, kfs, nb) in (("480p", 256, 20), ("720p", 256, 7)):
+        xs = max(5, args.steps // 2)
+        for kw in (dict(res="480p", kfs=256, N=20, disparity=args.disparity),                      # north_star target case
+                   dict(res="720p", kfs=256, N=7, disparity=args.disparity),                       # BASELINE configs[2]
+                   dict(res="480p", kfs=64, N=20, disparity=args.disparity, outliers=2,
+                        tag="configs[1] with 2 outlier (wrong-pose) neighbours per keyframe"),
+                   dict(res="480p", kfs=64, N=20, disparity=args.disparity, noise=True,
+                        tag="configs[1] geometry on i.i.d. uniform u8 images (SURVEY.md §8d adversarial set: scan-only rate)"),
+                   dict(res="480p", kfs=64, N=20, disparity=10.0,
+                        tag="configs[1] with a long baseline (adjacent-keyframe disparity 10 px)")):
             try:
-                extra.append(run_extra(pkg, torch, res, kfs, nb, args.disparity, max(5, args.steps // 2), 2,
-                                       local_rank, barrier))
+                extra.append(run_extra(pkg, torch, kw["res"], kw["kfs"], kw["N"], kw["disparity"], xs, 2, local_rank,
+                                       barrier, noise=kw.get("noise", False), outliers=kw.get("outliers", 0),
+                                       tag=kw.get("tag")))
             except Exception as e:  # the headline line must survive a failing extra
-                extra.append({"workload": "%s x %d KF x N=%d" % (res, kfs, nb), "error": repr(e)})
+                extra.append({"workload": kw.get("tag") or "%s x %d KF x N=%d" % (kw["res"], kw["kfs"], kw["N"]),
+                              "error": repr(e)})
         out["extra_configs"] = extra
     else:
         eng.close()

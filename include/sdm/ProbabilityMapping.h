@@ -95,6 +95,15 @@ public:
         std::lock_guard<std::mutex> lock(mutex_);
         keyframes.push_back(kf);
     }
+    void EraseKeyFrame(KeyFrame* kf) /* src/Map.cc:55-66: the pointer leaves the map; the object is the caller's */
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        for (size_t i = 0; i < keyframes.size(); i++)
+            if (keyframes[i] == kf) {
+                keyframes.erase(keyframes.begin() + i);
+                break;
+            }
+    }
 
 private:
     mutable std::mutex mutex_;

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "sdm_c.h"
@@ -31,16 +32,21 @@ struct RefConst {  // per reference keyframe of a batch
 };
 
 struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of the per-pixel code
+    // -- the first PCV_FLOATS (20) dwords are what K1's searches read; k_search_fuse stages exactly those in LDS --
     float F[9];                 // F12, PM.cc:972-986
-    float R[9];                 // R21, PM.cc:859 == 890 == 643
-    float t[3];                 // t21, PM.cc:860 == 891 == 644
+    float Rx[3];                // R21 row 0, PM.cc:859 == 890 == 643
+    float Rz[3];                // R21 row 2
+    float tx, tz;               // t21 x and z, PM.cc:860 == 891 == 644
     float rot;                  // median in-plane rotation, PM.cc:170-179
     float istd;                 // neighbour's I_stddev, PM.cc:457
+    int clean;                  // every angle the scan's two gates see lies in [0,360]: both keyframes' GradTheta planes
+                                // (checked when the records are packed) and rot in [-360,360] -- the closed-form gates
+                                // then hold for every candidate and the scan drops their per-candidate precondition
+    // -- the rest (K4, set-up) --
+    float Ry[3];                // R21 row 1
+    float ty;
     int nbr_slot;
     float nfx, nfy, ncx, ncy;  // neighbour intrinsics, PM.cc:675
-    int clean;                 // every angle the scan's two gates see lies in [0,360]: both keyframes' GradTheta planes
-                               // (checked when the records are packed) and rot in [-360,360] -- the closed-form gates
-                               // then hold for every candidate and the scan drops their per-candidate precondition
     float pad[3];
 };
 static_assert(sizeof(PairConst) == 128, "PairConst must stay 128 B");
@@ -365,9 +371,22 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 4  lerp weight from v_fract instead of floor + add + sub
 // bit 5  search range: min/max through v_med3 (no canonicalising v_max), clamps on the integers
 // bit 6  the in-plane-rotation wrap of PM.cc:425-426 with integer masks instead of compare + select
+// bit 7  (lost: +4 %) records through a buffer descriptor: hardware range check instead of the row clamp
+// bit 8  the per-(reference, neighbour) constants of a search are read from an LDS copy (-> vector registers) instead of
+//        scalar registers: an add / mul / fma with a scalar-register operand issues at the half rate of one without
+//        (tools/ubench/oprate.hip), and a search has ~40 of them
 #ifndef SDM_K1_OPT
-#define SDM_K1_OPT 0xff
+#define SDM_K1_OPT 0x7f
 #endif
+
+// what one search reads of its PairConst, as float indices into the block `cv` points at: the PairConst itself
+// (global memory -> scalar loads), or K1's compact LDS copy (k_search_fuse stages PCV_FLOATS floats per pair)
+constexpr int PCV_FLOATS = 20;  // leading dwords of PairConst (5 x 16 bytes)
+constexpr int CV_RX = 9, CV_RZ = 12, CV_TX = 15, CV_TZ = 16, CV_ROT = 17, CV_ISTD = 18;
+static_assert(offsetof(PairConst, Rx) == 4 * CV_RX && offsetof(PairConst, Rz) == 4 * CV_RZ && offsetof(PairConst, tx) == 4 * CV_TX &&
+                  offsetof(PairConst, tz) == 4 * CV_TZ && offsetof(PairConst, rot) == 4 * CV_ROT &&
+                  offsetof(PairConst, istd) == 4 * CV_ISTD && offsetof(PairConst, Ry) == 4 * PCV_FLOATS,
+              "the CV_* indices follow PairConst");
 
 // matching cost, PM.cc:436, with the guard of match_cost() as ONE unsigned comparison: the fast double sum is used
 // when 2^-99 <= s < 2^99 (inside the normal float range; negative, NaN and Inf patterns land outside) and its low 29
@@ -588,21 +607,24 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
 // nrec: the neighbour keyframe's record plane.  Returns true iff a hypothesis was produced
 // (dh.supported).  Normative choices N3-N5 for the reference's undefined behaviour: DESIGN.md §3.
+// cv: the pair's constants (layout CV_*); rcv: {fx, cx, min_depth, max_depth} of the reference keyframe;
+// clean: PairConst::clean (wave-uniform).
 template <bool STATS>
 __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
-                                                const PairConst* __restrict__ pc, float fx,
-                                                float cx, int x, int y, float pixel, float grad1,
-                                                float th_pi, float xp0, float xp1, float mind,
-                                                float maxd, const DevParams& prm, float& rho_o,
+                                                const float* __restrict__ cv, const float* __restrict__ rcv, int clean,
+                                                int x, int y, float pixel, float grad1,
+                                                float th_pi, float xp0, float xp1, const DevParams& prm, float& rho_o,
                                                 float& sigma_o, float& best_u, float& best_v,
                                                 SearchStats* st)
 {
+    float fx = rcv[0], cx = rcv[1];
+    const float mind = rcv[2], maxd = rcv[3];
     rho_o = 0.f;
     sigma_o = 0.f;
     best_u = 0.f;
     best_v = 0.f;
     if (STATS) st->searches++;
-    const float* F = pc->F;
+    const float* F = cv;
     float a = (float)x * F[0] + (float)y * F[3] + F[6];  // PM.cc:389-391
     float b = (float)x * F[1] + (float)y * F[4] + F[7];
     float c = (float)x * F[2] + (float)y * F[5] + F[8];
@@ -610,9 +632,9 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     if (!(ab >= -4 && ab <= 4)) return false;  // PM.cc:393; a NaN line yields no hypothesis
     float cb = c / b;
 
-    float rxxp = row_dot_xp(pc->R + 0, xp0, xp1);
-    float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-    float tx = pc->t[0], tz = pc->t[2];
+    float rxxp = row_dot_xp(cv + CV_RX, xp0, xp1);
+    float rzxp = row_dot_xp(cv + CV_RZ, xp0, xp1);
+    float tx = cv[CV_TX], tz = cv[CV_TZ];
     int lo, hi;
 #if SDM_K1_OPT & 0x20
     if (!search_range_int1(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
@@ -623,7 +645,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 
     // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
     float th_line = fast_atan2_deg_x1(-ab);
-    float ang_pi_rot = wrap_once_360(th_pi + pc->rot);  // PM.cc:424-426
+    float ang_pi_rot = wrap_once_360(th_pi + cv[CV_ROT]);  // PM.cc:424-426
 
     // closed-form gates need d < 360 and the default thresholds; with other thresholds the limit is -Inf and
     // every candidate takes the reference statement (a float limit keeps the test free of a uniform-bool VGPR)
@@ -643,7 +665,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     S.best_pixel = lo + 2;
 #endif
 #if SDM_K1_OPT & 0x02
-    if (pc->clean && prm.default_gates)  // wave-uniform (the pair's constants sit in scalar registers)
+    if (clean && prm.default_gates)  // wave-uniform
         scan_segment<STATS, true>(nbase, W, H, lo, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim, prm, S, st);
     else
 #endif
@@ -655,6 +677,18 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     rho_o = old_err + best_pe + (float)best_pixel;
     sigma_o = best_ge + 1.0f;
     return true;
+#endif
+
+#if SDM_K1_OPT & 0x100
+    // the constants the refinement needs are read again from the LDS copy instead of being carried through the scan in
+    // vector registers (the scan is where the register pressure peaks)
+    asm volatile("" ::: "memory");
+    fx = rcv[0];
+    cx = rcv[1];
+    tx = cv[CV_TX];
+    tz = cv[CV_TZ];
+    rxxp = row_dot_xp(cv + CV_RX, xp0, xp1);  // the same operations on the same operands: the same values
+    rzxp = row_dot_xp(cv + CV_RZ, xp0, xp1);
 #endif
 
     int up = best_pixel + 1, um = best_pixel - 1;  // PM.cc:449-450
@@ -676,7 +710,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float gpe = g * best_pe;
     float ustar = (float)((double)best_pixel +
                           ((double)gpe + inv_theta * (double)q * (double)best_ge) / (double)denom);
-    float ustar_var = 2 * pc->istd * pc->istd / denom;  // PM.cc:457
+    float ustar_var = 2 * cv[CV_ISTD] * cv[CV_ISTD] / denom;  // PM.cc:457
     best_u = ustar;
     best_v = -(ab * ustar + cb);  // PM.cc:460
 

@@ -1299,8 +1299,16 @@ int sdm_pair_geometry(sdm_ctx* c, int ref_slot, int nbr_slot, float F12[9], floa
     HIP_TRY(hipMemcpyAsync(&pc, c->d_pairs, sizeof(PairConst), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (F12) memcpy(F12, pc.F, sizeof(float) * 9);
-    if (R21) memcpy(R21, pc.R, sizeof(float) * 9);
-    if (t21) memcpy(t21, pc.t, sizeof(float) * 3);
+    if (R21) {
+        memcpy(R21, pc.Rx, sizeof(float) * 3);
+        memcpy(R21 + 3, pc.Ry, sizeof(float) * 3);
+        memcpy(R21 + 6, pc.Rz, sizeof(float) * 3);
+    }
+    if (t21) {
+        t21[0] = pc.tx;
+        t21[1] = pc.ty;
+        t21[2] = pc.tz;
+    }
     return SDM_OK;
 }
 

@@ -291,7 +291,16 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     KfMeta m1 = meta[ref_slots[r]];
     KfMeta m2 = meta[nbr_slots[idx]];
     PairConst pc;
-    pair_geometry(m1, m2, pc.F, pc.R, pc.t);
+    float R21[9], t21[3];
+    pair_geometry(m1, m2, pc.F, R21, t21);
+    for (int i = 0; i < 3; i++) {
+        pc.Rx[i] = R21[i];
+        pc.Ry[i] = R21[3 + i];
+        pc.Rz[i] = R21[6 + i];
+    }
+    pc.tx = t21[0];
+    pc.ty = t21[1];
+    pc.tz = t21[2];
     pc.rot = rot ? rot[idx] : 0.0f;
     pc.istd = m2.I_stddev;
     pc.nbr_slot = nbr_slots[idx];
@@ -449,12 +458,23 @@ constexpr int K1_BLOCK = K1_PX * K1_WAVES;
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
     const size_t nn = (size_t)(n > 0 ? n : 1);
+#if SDM_K1_OPT & 0x100
+    return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
+           sizeof(unsigned long long) * K1_PX + sizeof(unsigned) * K1_PX + sizeof(float) * ((size_t)PCV_FLOATS * nn + 4);
+#else
     return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
            sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned) * K1_PX;
+#endif
 }
 
+// 8 waves per SIMD (64 vector registers): with the search constants in vector registers (SDM_K1_OPT bit 8) hipcc would
+// otherwise take 66 and lose a wave; the registers it spills instead live in the exact-division fallback of the matching
+// cost, which runs for about one candidate in 10^5
+#ifndef SDM_K1_EU_MIN
+#define SDM_K1_EU_MIN 8
+#endif
 #ifndef SDM_K1_LB
-#define SDM_K1_LB __launch_bounds__(K1_BLOCK)
+#define SDM_K1_LB __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(SDM_K1_EU_MIN, 8)))
 #endif
 template <bool STATS>
 __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long long plane,
@@ -473,8 +493,15 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     // wave-uniform, so the shift is a scalar; a 32-bit LDS atomic add of 1<<8*(a&3) cannot carry over.
     unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
     const int cnt_words = (n + 3) >> 2;
+#if SDM_K1_OPT & 0x100
+    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [64], OR of the waves' masks
+    unsigned* cnt0 = reinterpret_cast<unsigned*>(pmask + K1_PX);  // [64] size of the FIRST hypothesis' compatible set
+    float* lref = reinterpret_cast<float*>(cnt0 + K1_PX);        // {fx, cx, mind, maxd} + [n][PCV_FLOATS] search constants
+    float* lcv = lref + 4;
+#else
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
     unsigned* cnt0 = reinterpret_cast<unsigned*>(pmask + K1_BLOCK);  // [64] size of the FIRST hypothesis' compatible set
+#endif
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -508,6 +535,26 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     }
     SearchStats st = {0, 0, 0};
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
+#if SDM_K1_OPT & 0x100
+    if (w == 0) pmask[p] = 0ull;
+    // the searches read their per-pair constants from this LDS copy, i.e. into VECTOR registers: float add / mul with
+    // a scalar-register operand issue at half the rate (sdm_device.h, bit 8)
+    {
+        // 5 x 16 bytes per pair: thread t copies quad t%5 of pair t/5
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(pcs);
+        float4* dst = reinterpret_cast<float4*>(lcv);
+        for (int i = tid; i < n * (PCV_FLOATS / 4); i += K1_BLOCK) {
+            const int j = (i * 205) >> 10;  // i / 5 for i < 1024 (n <= 64 pairs: i < 320)
+            dst[i] = src[j * (int)(sizeof(PairConst) / sizeof(float4)) + (i - 5 * j)];
+        }
+        if (tid < 4) lref[tid] = (tid == 0) ? rc.fx : (tid == 1) ? rc.cx : (tid == 2) ? rc.mind : rc.maxd;
+    }
+    __syncthreads();
+    const float* __restrict__ rcv = lref;
+#else
+    const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
+    const float* __restrict__ rcv = rcvb;
+#endif
     // Hypotheses go to LDS in neighbour order.  "No hypothesis" (PM.cc:216) is stored as rho = +Inf,
     // sigma = 1: against any real hypothesis the squared difference is +Inf, so the compatibility
     // test fails on its fast path and the pair loops need no validity checks.  Each wave also keeps
@@ -519,8 +566,13 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         float2 h = make_float2(__builtin_inff(), 1.0f);
         if (on) {
             float rho, sigma, bu, bv;
-            bool ok = epipolar_search<STATS>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, grad1, th_pi, xp0, xp1,
-                                             rc.mind, rc.maxd, prm, rho, sigma, bu, bv, &st);
+#if SDM_K1_OPT & 0x100
+            const float* __restrict__ cv = lcv + j * PCV_FLOATS;
+#else
+            const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
+#endif
+            bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
+                                             sigma, bu, bv, &st);
             if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
                 h = make_float2(rho, sigma);
                 mymask |= 1ull << j;
@@ -531,7 +583,11 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     }
     for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
     if (w == 0) cnt0[p] = 0u;
+#if SDM_K1_OPT & 0x100
+    if (mymask) atomicOr(&pmask[p], mymask);
+#else
     pmask[tid] = mymask;
+#endif
     __syncthreads();
 
     // InverseDepthHypothesisFusion, PM.cc:598-626.  ChiTest is symmetric bit for bit (the squared
@@ -540,9 +596,13 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     // waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.  Wave 0
     // then takes the first row with the largest count (PM.cc:616: strict '>') and re-derives only
     // that row's membership for the fusion sum.
+#if SDM_K1_OPT & 0x100
+    const unsigned long long vm = pmask[p];
+#else
     unsigned long long vm = 0;
 #pragma unroll
     for (int q = 0; q < K1_WAVES; q++) vm |= pmask[q * K1_PX + p];
+#endif
 #if SDM_ABLATE == 1
     const int nh = 0;
     if (vm == 0x123456789ull) pool[0] = make_float2(1.f, 1.f);
@@ -956,14 +1016,14 @@ __device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ 
 {
     int kf_count = in.kf_count;
     float sum_Jr = in.sum_Jr, sum_JJ = in.sum_JJ;
-    float t0 = row_dot_xp(pc->R + 0, xp0, xp1) / depthp + pc->t[0];  // PM.cc:678
-    float t1 = row_dot_xp(pc->R + 3, xp0, xp1) / depthp + pc->t[1];
-    float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
-    float t2 = rzxp / depthp + pc->t[2];
+    float t0 = row_dot_xp(pc->Rx, xp0, xp1) / depthp + pc->tx;  // PM.cc:678
+    float t1 = row_dot_xp(pc->Ry, xp0, xp1) / depthp + pc->ty;
+    float rzxp = row_dot_xp(pc->Rz, xp0, xp1);
+    float t2 = rzxp / depthp + pc->tz;
     float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
     float v = pc->nfy * t1 + pc->ncy * t2;
     float xj = u / t2, yj = v / t2;  // PM.cc:680
-    float denom2 = depthp * pc->t[2];
+    float denom2 = depthp * pc->tz;
     float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
     if (!(xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1)) return in;  // PM.cc:695
     int x0 = (int)floorf(xj), y0 = (int)floorf(yj);
@@ -982,7 +1042,7 @@ __device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ 
         float djn = 1 / h[k].x;  // PM.cc:777-783
         float d2sigma = djn * djn * h[k].y;
         float J = (-rzxp) / d2sigma;                          // PM.cc:782
-        float r0 = (djn - dp * rzxp - pc->t[2]) / d2sigma;    // PM.cc:783
+        float r0 = (djn - dp * rzxp - pc->tz) / d2sigma;    // PM.cc:783
         sum_Jr = sum_Jr + J * r0;
         sum_JJ = sum_JJ + J * J;
     }
@@ -998,12 +1058,12 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
 {
     const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
     K4Guard g = g0;
-    const float n0 = row_dot_xp(pc->R + 0, xp0, xp1), n1 = row_dot_xp(pc->R + 3, xp0, xp1);
-    const float rzxp = row_dot_xp(pc->R + 6, xp0, xp1);
+    const float n0 = row_dot_xp(pc->Rx, xp0, xp1), n1 = row_dot_xp(pc->Ry, xp0, xp1);
+    const float rzxp = row_dot_xp(pc->Rz, xp0, xp1);
     guard2(g, n0, n1);
-    const float t0 = quot_fast(n0, depthp, dp) + pc->t[0];  // PM.cc:678
-    const float t1 = quot_fast(n1, depthp, dp) + pc->t[1];
-    const float t2 = quot_fast(rzxp, depthp, dp) + pc->t[2];
+    const float t0 = quot_fast(n0, depthp, dp) + pc->tx;  // PM.cc:678
+    const float t1 = quot_fast(n1, depthp, dp) + pc->ty;
+    const float t2 = quot_fast(rzxp, depthp, dp) + pc->tz;
     guard2(g, rzxp, t2);
     guard_divisor(g, t2);
     const float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
@@ -1011,7 +1071,7 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
     guard2(g, u, v);
     const float r2 = rcp_fast(t2);
     const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
-    const float denom2 = depthp * pc->t[2];
+    const float denom2 = depthp * pc->tz;
     const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
     const bool valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
     // lanes that project outside fetch pixel (0,0): the loads stay unconditional, their taps never count
@@ -1049,7 +1109,7 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
         const float d2sigma = djn * djn * sg;
         const float rd = rcp_fast(d2sigma);
         const float J = quot_fast(-rzxp, d2sigma, rd);  // PM.cc:782
-        float rnum = djn - dp * rzxp - pc->t[2];        // PM.cc:783
+        float rnum = djn - dp * rzxp - pc->tz;        // PM.cc:783
         rnum = c ? rnum : 1.0f;
         const float r0 = quot_fast(rnum, d2sigma, rd);
         rn[k] = rnum;
@@ -1290,8 +1350,9 @@ __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long p
     float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;
     float rho, sigma, bu, bv;
     SearchStats st = {0, 0, 0};
-    bool ok = epipolar_search<false>(nrec, W, H, pc, rc.fx, rc.cx, x, y, pixel, r.x, r.y, xp0, xp1, rc.mind,
-                                     rc.maxd, prm, rho, sigma, bu, bv, &st);
+    const float* cv = reinterpret_cast<const float*>(pc);
+    const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
+    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st);
     out[0] = rho;
     out[1] = sigma;
     out[2] = ok ? 1.f : 0.f;
@@ -1304,9 +1365,9 @@ __global__ void k_search_range_px(const RefConst* refs, const PairConst* pairs, 
 {
     const RefConst rc = refs[0];
     float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;
-    float rxxp = row_dot_xp(pairs->R + 0, xp0, xp1), rzxp = row_dot_xp(pairs->R + 6, xp0, xp1);
+    float rxxp = row_dot_xp(pairs->Rx, xp0, xp1), rzxp = row_dot_xp(pairs->Rz, xp0, xp1);
     float umin, umax;
-    search_range(rc.fx, rc.cx, rxxp, rzxp, pairs->t[0], pairs->t[2], rc.mind, rc.maxd, W, umin, umax);
+    search_range(rc.fx, rc.cx, rxxp, rzxp, pairs->tx, pairs->tz, rc.mind, rc.maxd, W, umin, umax);
     out[0] = umin;
     out[1] = umax;
 }
@@ -1396,9 +1457,14 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
         const unsigned mode = xs32(s) & 7u;
         // geometry: near-identity rotation rows, small translation, pixel-scale intrinsics; sometimes wild
         const float wild = (mode == 0) ? 1.0f : 0.0f;
-        for (int i = 0; i < 9; i++) pc->R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + (st_uniform(s) - 0.5f) * (0.1f + wild);
-        for (int i = 0; i < 3; i++) pc->t[i] = (st_uniform(s) - 0.5f) * (0.2f + 10.0f * wild);
-        if (mode == 1) pc->t[2] = 0.0f;
+        for (int i = 0; i < 9; i++) {
+            float* row = (i < 3) ? pc->Rx : (i < 6) ? pc->Ry : pc->Rz;
+            row[i % 3] = ((i % 4 == 0) ? 1.0f : 0.0f) + (st_uniform(s) - 0.5f) * (0.1f + wild);
+        }
+        pc->tx = (st_uniform(s) - 0.5f) * (0.2f + 10.0f * wild);
+        pc->ty = (st_uniform(s) - 0.5f) * (0.2f + 10.0f * wild);
+        pc->tz = (st_uniform(s) - 0.5f) * (0.2f + 10.0f * wild);
+        if (mode == 1) pc->tz = 0.0f;
         pc->nfx = 1.0f + st_uniform(s);
         pc->nfy = 1.0f + st_uniform(s);
         pc->ncx = 0.5f + st_uniform(s);
@@ -1408,8 +1474,8 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
         if (mode == 3) depthp = __uint_as_float((__float_as_uint(depthp) | 0x7FFFFFu));  // significand all ones
         const float dp = rcp_exact(depthp);
         // what rho_j will be for this geometry (any value works; used to put the taps near the threshold)
-        const float rz = row_dot_xp(pc->R + 6, xp0, xp1);
-        const float depthj = depthp / (rz + depthp * pc->t[2]);
+        const float rz = row_dot_xp(pc->Rz, xp0, xp1);
+        const float depthj = depthp / (rz + depthp * pc->tz);
         for (int k = 0; k < 6; k++) {
             float sg = (mode == 4) ? st_logmag(s, -30.f, 30.f) : st_logmag(s, -9.f, -2.f);
             const float crit = 1.9595918f * sg;  // sqrt(3.84) sigma

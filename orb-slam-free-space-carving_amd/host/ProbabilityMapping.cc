@@ -494,7 +494,8 @@ bool ProbabilityMapping::InitSharding(const unsigned char* comm_id, int world, i
 // keeps the two stage flags replicated: after a pass it sets them on every keyframe that ANY rank reconstructed or
 // checked, see the end of that function).  The C++ counterpart of shard.py's plan().  Blocks are equal and contiguous:
 // owner(i) = i / count.
-//   refs   keyframes reconstructed in this pass (PM.cc:141,160: good, not yet semidense, covisN good+mapped neighbours)
+//   refs   keyframes reconstructed in this pass (PM.cc:141,157,160: good, mapped, not yet semidense, covisN good+mapped
+//          neighbours)
 //   check  keyframes checked in this pass (PM.cc:265-298: good, not yet checked, semidense by the end of this pass's
 //          reconstruction, covisN neighbours that are ALL semidense by then) -- the reference's gate: a keyframe whose
 //          neighbour has no depth map yet is not checked, and nobody sends or receives a map that does not exist
@@ -527,7 +528,7 @@ bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int f
     for (int i = 0; i < n_all; i++) {
         if (all[i]->isBad()) continue;
         nb_all[i] = nbr_idx(i);
-        if (!all[i]->semidense_flag_ && !nb_all[i].empty()) out->recon_all[i] = 1;
+        if (!all[i]->semidense_flag_ && all[i]->Mapped() && !nb_all[i].empty()) out->recon_all[i] = 1;  // PM.cc:141,157,160
     }
     auto will_have_map = [&](int j) { return all[j]->semidense_flag_ || out->recon_all[j]; };
     for (int i = 0; i < n_all; i++) {

@@ -3,6 +3,7 @@
 // with shard.plan (the Python plan the bench and the multi-rank tests use).  Host logic only: no device call is made.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "sdm/ProbabilityMapping.h"
@@ -29,15 +30,41 @@ int main(int argc, char** argv)
         }
         all.push_back(&kfs[k]);
     }
-    if (argc > 4) kfs[atoi(argv[4])].bad = true;              // a bad keyframe is skipped as a reference and as a neighbour
-    if (argc > 5) kfs[atoi(argv[5])].semidense_flag_ = true;  // an already reconstructed one is not a reference again
+    const bool twopass = argc > 4 && std::string(argv[4]) == "twopass";
+    if (!twopass) {
+        if (argc > 4) kfs[atoi(argv[4])].bad = true;              // a bad keyframe is skipped as a reference and as a neighbour
+        if (argc > 5) kfs[atoi(argv[5])].semidense_flag_ = true;  // an already reconstructed one is not a reference again
+    }
     const int count = n_all / world;
+    if (twopass) {
+        // Pass 1 with some keyframes not yet mapped (LocalMapping still busy with them), then pass 2 after they became
+        // usable.  Between the passes every rank applies what SemiDenseReconBlock applies: the stage flags of every
+        // keyframe ANY rank reconstructed / checked (BlockPlan::recon_all / check_all) -- the state the next plan is
+        // derived from is replicated, so the pass-2 lists printed below must match pairwise (with flags
+        // set only on a rank's own keyframes the second pass deadlocked).
+        for (int k = 0; k < n_all; k++) kfs[k].mapped = (k % 5 != 3);
+        sdm::BlockPlan p1;
+        if (!ProbabilityMapping::PlanBlock(all, 0, count, world, 0, n, &p1)) return 3;
+        for (int r = 1; r < world; r++) {  // every rank derives the same replicated part
+            sdm::BlockPlan pr;
+            if (!ProbabilityMapping::PlanBlock(all, r * count, count, world, r, n, &pr)) return 3;
+            if (pr.recon_all != p1.recon_all || pr.check_all != p1.check_all) return 6;
+        }
+        for (int k = 0; k < n_all; k++) {
+            if (p1.recon_all[k]) kfs[k].semidense_flag_ = true;
+            if (p1.check_all[k]) kfs[k].interKF_depth_flag_ = true;
+            kfs[k].mapped = true;
+        }
+    }
     for (int r = 0; r < world; r++) {
         sdm::BlockPlan pl;
         if (!ProbabilityMapping::PlanBlock(all, r * count, count, world, r, n, &pl)) return 3;
         std::printf("rank %d", r);
         dump("refs", pl.refs);
-        std::vector<int> needed, boundary, flat;
+        dump("check", pl.check);
+        std::vector<int> needed, boundary, flat, cflat;
+        for (const std::vector<int>& row : pl.check_nbrs) cflat.insert(cflat.end(), row.begin(), row.end());
+        dump("check_nbrs", cflat);
         for (int i = 0; i < n_all; i++) {
             if (pl.needed[i]) needed.push_back(i);
             if (pl.boundary[i]) boundary.push_back(i);

@@ -120,17 +120,57 @@ int main()
     std::set<ORB_SLAM2::KeyFrame*> adj;
     adj.insert(&kfs[4]);
     adj.insert(&kfs[0]);  // never mapped: ignored
-    q.OnPosesAdjusted(adj);
+    q.OnPosesAdjusted(adj);  // any thread: only queues the new poses ...
+    CHECK(mapper.update_all == 0 && !q.Find(&kfs[4])->poseChanged);
+    kfs[4].Tcw.at<float>(0, 3) = 0.75f;  // (the pose was copied when the hook ran; a later change is a later event)
+    CHECK(q.DrainEvents() == 2);  // ... the Modeler thread applies them
     CHECK(mapper.update_all == 1 && q.Find(&kfs[4])->poseChanged && q.Find(&kfs[4])->Tcw[3] == 0.25f && !q.Find(&kfs[1])->poseChanged);
 
     // the SLAM side erases kfs[1] while it is queued again
     q.Enqueue(&kfs[1]);
     q.Enqueue(&kfs[4]);
     sdm::KeyFrame* s1 = q.Find(&kfs[1]);
-    q.OnKeyFrameErased(&kfs[1]);
+    q.OnKeyFrameErased(&kfs[1]);  // any thread: leaves the work queue at once, the rest is queued for the Modeler thread
+    CHECK(q.Pending() == 1 && q.Find(&kfs[1]) == s1 && mapper.forgotten.empty());
+    CHECK(q.DrainEvents() == 1);
     CHECK(q.Pending() == 1 && q.Find(&kfs[1]) == nullptr && mapper.forgotten.size() == 1 && mapper.forgotten[0] == s1);
     CHECK(map.keyframes.size() == 1 && map.keyframes[0] == q.Find(&kfs[4]) && q.Find(&kfs[4])->covisible.empty());
     q.OnKeyFrameErased(&kfs[0]);  // unknown keyframe: no-op
+    CHECK(q.DrainEvents() == 1 && map.keyframes.size() == 1);
+
+    // a finished keyframe that turned bad, or whose erasure is still queued, is not handed to the mesher
+    // (Modeler.cc:112-116); every injection happens between SetNotErase and SetErase
+    {
+        std::vector<ORB_SLAM2::KeyFrame> k2(4);
+        for (int i = 0; i < 4; i++) {
+            k2[i] = kfs[4];
+            k2[i].mnId = 50 + i;
+            k2[i].mnFrameId = 200 + i;
+            k2[i].bad = false;
+            k2[i].pins = k2[i].unpins = k2[i].not_erase = 0;
+            k2[i].cov.clear();
+        }
+        FakeMapper m2;
+        m2.lag = 1;
+        sdm::Map map2;
+        std::vector<ORB_SLAM2::KeyFrame*> inj2;
+        std::vector<int> pinned_at_injection;
+        auto inject2 = [&](ORB_SLAM2::KeyFrame* k, std::vector<cv::Point3f>&) {
+            inj2.push_back(k);
+            pinned_at_injection.push_back(k->not_erase);
+        };
+        sdm_adapter::SemiDenseQueueT<FakeMapper> q2(&m2, &map2, image, inject2, 8);
+        for (int i = 0; i < 4; i++) q2.Enqueue(&k2[i]);
+        CHECK(q2.ProcessOne());        // k2[0] reconstructed
+        k2[0].bad = true;              // ... and culled by the SLAM side before it is finished
+        CHECK(q2.ProcessOne());        // k2[1]: finishes k2[0], which is bad -> not injected
+        CHECK(inj2.empty());
+        q2.OnKeyFrameErased(&k2[1]);   // erasure queued (not drained yet) ...
+        m2.lag = 0;                    // (from now on a keyframe is finished by its own call)
+        CHECK(q2.ProcessOne());        // k2[2]: drains the erasure first, finishes k2[2] itself -> injected, pinned
+        CHECK(inj2.size() == 1 && inj2[0] == &k2[2] && pinned_at_injection[0] == 2);  // ProcessOne's pin + the injection's
+        CHECK(k2[2].not_erase == 0 && q2.Find(&k2[1]) == nullptr);
+    }
     std::printf("OK\n");
     return 0;
 }

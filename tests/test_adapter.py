@@ -63,7 +63,8 @@ def test_cpp_block_plan_equals_python_plan(pkg, tmp_path):
         assert len(got) == world
         for r, g in enumerate(got):
             pl = pkg.shard.plan(n_all, world, r, n, nb)
-            assert g["refs"] == pl["own"]
+            assert g["refs"] == pl["own"] and g["check"] == pl["own"]
+            assert g["check_nbrs"] == g["nbrs"]
             assert g["nbrs"] == [j for row in pl["nbrs"] for j in row]
             assert g["needed"] == pl["inputs"]
             assert g["boundary"] == pl["boundary"]
@@ -80,3 +81,29 @@ def test_cpp_block_plan_equals_python_plan(pkg, tmp_path):
                 r_ = [k for p, k in zip(got[b]["recv_peer"], got[b]["recv_kf"]) if p == a]
                 assert s == r_, (a, b, s, r_)
     assert 9 not in got[1]["refs"] and 17 not in got[2]["refs"] and 9 not in got[1]["nbrs"]
+
+
+def test_cpp_block_plan_second_pass_is_pairwise_consistent(pkg, tmp_path):
+    """A second sharded pass (keyframes that became usable after the first) is planned from replicated flags only: on
+    every rank pair the k-th send equals the k-th receive, nobody sends or reads a map that does not exist, already
+    reconstructed or checked keyframes are not processed again (PM.cc:141, 265)."""
+    n_all, world, n = 40, 4, 6
+    got = _plan_block(pkg, tmp_path, n_all, world, n, extra=("twopass",))
+    late = {k for k in range(n_all) if k % 5 == 3}
+    all_refs, all_check = set(), set()
+    for a in range(world):
+        for b in range(world):
+            if a != b:
+                s = [k for p, k in zip(got[a]["send_peer"], got[a]["send_kf"]) if p == b]
+                r_ = [k for p, k in zip(got[b]["recv_peer"], got[b]["recv_kf"]) if p == a]
+                assert s == r_, (a, b, s, r_)
+        count = n_all // world
+        assert all(a * count <= k < (a + 1) * count for k in got[a]["refs"] + got[a]["check"])
+        all_refs.update(got[a]["refs"])
+        all_check.update(got[a]["check"])
+        recv = set(got[a]["recv_kf"])
+        own = set(range(a * count, (a + 1) * count))
+        assert recv == set(got[a]["check_nbrs"]) - own  # exactly the maps this rank's checks read from elsewhere
+    assert all_refs == late  # pass 2 reconstructs the late keyframes only
+    assert all_check == late  # and checks them (everything else was checked in pass 1, against the neighbours it had then)
+    assert sum(len(g["recv_kf"]) for g in got) > 0  # their checks read maps reconstructed by other ranks in pass 1

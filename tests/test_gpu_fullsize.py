@@ -232,6 +232,140 @@ def test_config4_one_rank_share_1080p_256kf(pkg, oracle, gpu_ok):
     eng.close()
 
 
+def _as_bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+def test_config4_full_2048kf_1080p(pkg, oracle, gpu_ok):
+    """BASELINE.json configs[3] at its FULL size on one MI355X: 1920x1080 x 2048 keyframes, N = 7, all resident in one
+    engine (2048 slots x 44 B/px x 2.07 Mpx = 187 GB of the 288 GB).
+      (a) single engine: K1-K5 over all 2048 keyframes; structural properties on every 8th keyframe; the first keyframe,
+          both sides of a block boundary (767 | 768) and the last keyframe bit-equal to the oracle through K1-K5;
+      (b) the SAME sequence as the eight rank shares of the 8-GPU run, one after another on this GPU: shard.plan's local
+          slots (256 own + covisible halo), K1-K3 of the own block, the exchange replaced by sdm_upload_depth of the
+          owners' maps (taken from the single engine), K4 + K5 -- every own keyframe of every share equals the
+          single-engine result bit for bit ({rho, sigma} after K3 and the checked rho, compared on the device).
+    This pins the sharding at full size without eight GPUs; the RCCL transport itself stays unmeasured here."""
+    cam, n, n_total, world = pkg.synth.HD1080, 7, 2048, 8
+    W, H = cam["W"], cam["H"]
+    free, _ = torch.cuda.mem_get_info()
+    if free < 245e9:
+        pytest.skip("needs 245 GB of free HBM (187 GB engine + 24 GB share + 34 GB comparison planes); %.0f GB free" % (free / 1e9))
+    scene = pkg.synth.Scene(cam, 0x5EED0004)
+    Kc = scene.K()
+    mn, mx = scene.depth_prior()
+    # engines run on their own streams; every hand-over between torch and an engine below is bracketed by
+    # torch.cuda.synchronize() / eng.synchronize()
+    pool = torch.zeros((n_total, H, W, 2), dtype=torch.float32, device="cuda")  # the depth maps, torch-owned (34 GB)
+    torch.cuda.synchronize()
+    eng = pkg.Engine(W, H, n_total, max_neighbours=n, batch_capacity=64, with_pointset=True,
+                     ext_depth_pool=pool.data_ptr())
+    oracle_kfs = (0, 767, 768, 2047)
+    refs = list(range(n_total))
+    nbrs = [scene.neighbours(k, n_total, n) for k in refs]
+    keep = set(oracle_kfs) | {j for k in oracle_kfs for j in nbrs[k]}
+    ims = {}
+    for k in refs:
+        im, _ = scene.render(k, device="cuda")
+        torch.cuda.synchronize()
+        eng.upload_image_device(k, im.data_ptr(), Kc, scene.Tcw(k))
+        if k in keep:
+            ims[k] = im.cpu().numpy()
+    eng.recon(refs, nbrs, mn, mx)
+    eng.synchronize()
+    # what the eight ranks would exchange: every keyframe some other rank's K4 reads, as finished K3 maps
+    plans = [pkg.shard.plan(n_total, world, r, n, scene.neighbours) for r in range(world)]
+    crossing = sorted({k for pl in plans for lst in pl["recv"].values() for k in lst})
+    assert 0 < len(crossing) <= world * n
+    sent = {k: eng.download_depth(k) for k in crossing}
+    k3 = {k: eng.download_depth(k) for k in keep}
+    eng.inter_check_pointset(refs, nbrs, commit=False)
+    eng.synchronize()
+    # ---- (a) properties on every 8th keyframe, oracle on the four named ones
+    sup = 0
+    for k in refs[::8]:
+        r = pool[k, :, :, 0].cpu().numpy()
+        c = eng.download_checked(k)
+        assert not r[:2].any() and not r[-2:].any() and not r[:, :2].any() and not r[:, -2:].any()  # PM.cc:198-199
+        assert not ((c > 1e-6) & ~(r > 1e-6)).any()  # the check only removes or refines support (PM.cc:762-794)
+        sup += int((c > 1e-6).sum())
+    assert sup > 0.05 * (n_total // 8) * W * H, "semi-dense coverage"
+    for k in oracle_kfs:
+        kf = {}
+        for j in [k] + nbrs[k]:
+            g, t, s_ = oracle.gradient_prepass(ims[j])
+            kf[j] = oracle.keyframe(ims[j], g, t, s_, Kc, scene.Tcw(j))
+        r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in nbrs[k]], None, mn, mx)
+        assert_bit_equal(k3[k][0], r, "rho kf %d" % k)
+        assert_bit_equal(k3[k][1], s, "sigma kf %d" % k)
+        c = oracle.inter_check(kf[k], r, [kf[j] for j in nbrs[k]], [k3[j][0] for j in nbrs[k]], [k3[j][1] for j in nbrs[k]])
+        assert_bit_equal(eng.download_checked(k), c, "checked rho kf %d" % k)
+        assert_bit_equal(eng.download_pointset(k), oracle.pointset(kf[k], c), "xyz kf %d" % k)
+    del ims, k3
+    # ---- (b) the eight rank shares, one after another
+    chk_all = torch.zeros((n_total, H, W), dtype=torch.float32, device="cuda")  # the shares' checked rho (17 GB)
+    torch.cuda.synchronize()
+    n_cross = 0
+    for pl in plans:
+        assert pl["count"] == 256 and pl["n_slots"] <= 256 + n
+        spool = torch.zeros((pl["n_slots"], H, W, 2), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        sh = pkg.Engine(W, H, pl["n_slots"], max_neighbours=n, batch_capacity=64, with_pointset=True,
+                        ext_depth_pool=spool.data_ptr())
+        for k in pl["inputs"]:
+            im, _ = scene.render(k, device="cuda")
+            torch.cuda.synchronize()
+            sh.upload_image_device(pl["slot"][k], im.data_ptr(), Kc, scene.Tcw(k))
+        own, onb = pl["own_slots"], pl["nbr_slots"]
+        sh.recon(own, onb, mn, mx)
+        for peer in sorted(pl["recv"]):  # the exchange: the owner's finished maps arrive in the halo slots
+            for k in pl["recv"][peer]:
+                sh.upload_depth(pl["slot"][k], *sent[k])
+                n_cross += 1
+        sh.synchronize()
+        fs, f0 = pl["first_slot"], pl["first"]
+        assert torch.equal(_as_bits(spool[fs:fs + 256]), _as_bits(pool[f0:f0 + 256])), "rank %d: {rho,sigma} after K3" % pl["rank"]
+        sh.inter_check_pointset(own, onb, commit=True)  # commit: the checked rho lands in the pool tensor
+        sh.synchronize()
+        chk_all[f0:f0 + 256] = spool[fs:fs + 256, :, :, 0]
+        torch.cuda.synchronize()
+        if pl["rank"] in (0, 3):  # K5 of a share against the single engine, two keyframes each
+            for k in (f0, f0 + 255):
+                assert_bit_equal(sh.download_pointset(pl["slot"][k]), eng.download_pointset(k), "xyz kf %d" % k)
+        sh.close()
+        del spool
+    assert n_cross == len(crossing) or n_cross > len(crossing)  # a map may go to two ranks
+    eng.inter_check(refs, nbrs, commit=True)  # same snapshot semantics; rho of the pool tensor becomes the checked rho
+    eng.synchronize()
+    assert torch.equal(_as_bits(pool[:, :, :, 0]), _as_bits(chk_all)), "checked rho: the eight shares vs the single engine"
+    assert int((chk_all > 1e-6).sum()) > 0.05 * n_total * W * H
+    eng.close()
+
+
+def test_config5_eight_independent_sequences(pkg, oracle, gpu_ok):
+    """BASELINE.json configs[4]: eight independent 640x480 sequences (seeds 0x5EED0050..57, 64 keyframes x N = 20), the
+    per-GPU workloads of `bench.py --independent`, here one after another on one GPU.  Every keyframe of every sequence
+    goes through the property checks; one keyframe per sequence (a different one each time) is bit-equal to the oracle
+    through K1-K5."""
+    for q in range(8):
+        seq = GpuSequence(pkg, pkg.synth.TUM1, 64, 20, 0x5EED0050 + q, keep_images=())
+        maps, chk = run_all(seq)
+        k = (5 + 8 * q) % 64
+        xyz = {j: seq.eng.download_pointset(j) for j in (0, k, 63)}
+        sup = check_properties(seq, maps, chk, xyz, acc_tol=2e-3)
+        assert sup > 0.10 * 64 * 640 * 480, "semi-dense coverage (sequence %d)" % q
+        kf = {j: seq.oracle_kf(oracle, j) for j in [k] + seq.nbrs[k]}
+        r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in seq.nbrs[k]], None, seq.min_d, seq.max_d)
+        assert_bit_equal(maps[k][0], r, "sequence %d: rho kf %d" % (q, k))
+        assert_bit_equal(maps[k][1], s, "sequence %d: sigma kf %d" % (q, k))
+        c = oracle.inter_check(kf[k], r, [kf[j] for j in seq.nbrs[k]], [maps[j][0] for j in seq.nbrs[k]],
+                               [maps[j][1] for j in seq.nbrs[k]])
+        assert_bit_equal(chk[k], c, "sequence %d: checked rho kf %d" % (q, k))
+        assert_bit_equal(xyz[k], oracle.pointset(kf[k], c), "sequence %d: xyz kf %d" % (q, k))
+        seq.eng.close()
+        del seq, maps, chk
+
+
 def test_external_pool_and_stream(pkg, oracle, gpu_ok):
     """the bench's plumbing: depth pool owned by torch (what RCCL all-gathers in place) and the
     engine running on a torch stream; the pool tensor IS the depth map"""
