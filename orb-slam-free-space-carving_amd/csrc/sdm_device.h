@@ -372,9 +372,7 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 5  search range: min/max through v_med3 (no canonicalising v_max), clamps on the integers
 // bit 6  the in-plane-rotation wrap of PM.cc:425-426 with integer masks instead of compare + select
 // bit 7  (lost: +4 %) records through a buffer descriptor: hardware range check instead of the row clamp
-// bit 8  the per-(reference, neighbour) constants of a search are read from an LDS copy (-> vector registers) instead of
-//        scalar registers: an add / mul / fma with a scalar-register operand issues at the half rate of one without
-//        (tools/ubench/oprate.hip), and a search has ~40 of them
+// bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
 #ifndef SDM_K1_OPT
 #define SDM_K1_OPT 0x7f
 #endif
@@ -679,17 +677,6 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     return true;
 #endif
 
-#if SDM_K1_OPT & 0x100
-    // the constants the refinement needs are read again from the LDS copy instead of being carried through the scan in
-    // vector registers (the scan is where the register pressure peaks)
-    asm volatile("" ::: "memory");
-    fx = rcv[0];
-    cx = rcv[1];
-    tx = cv[CV_TX];
-    tz = cv[CV_TZ];
-    rxxp = row_dot_xp(cv + CV_RX, xp0, xp1);  // the same operations on the same operands: the same values
-    rzxp = row_dot_xp(cv + CV_RZ, xp0, xp1);
-#endif
 
     int up = best_pixel + 1, um = best_pixel - 1;  // PM.cc:449-450
     if (um < 0 || up > W - 1) return false;

@@ -63,6 +63,13 @@ struct sdm_ctx {
     unsigned* d_act = nullptr;     // [max_keyframes][P] active-pixel lists (y<<16|x), raster order
     int* d_act_count = nullptr;    // [max_keyframes]
     int* d_theta_bad = nullptr;    // [max_keyframes] GradTheta plane holds a value outside [0,360] (k_pack)
+    // K1's open-pixel list (pixels whose fusion the bounds do not settle; finished by k_fuse_open)
+    unsigned* d_open_ctr = nullptr;  // two {count, first overflow} pairs, used alternately by successive launches
+    long long* d_open_pix = nullptr;
+    unsigned long long* d_open_vm = nullptr;
+    float2* d_open_hyp = nullptr;
+    unsigned open_capacity = 0;
+    unsigned open_launch = 0;
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
     bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
@@ -245,6 +252,19 @@ size_t select_set(sdm_ctx* c, int si, int n_ref, size_t np)
 }
 
 int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+// One dispatch stays below 2^30 work-items.  A launch of 2^31 or more (still below HIP's documented 2^32 limit) runs, but
+// not over the whole grid on this stack: K1 over 2048 keyframes of 1920x1080 in ONE launch (14.8 M workgroups x 256 =
+// 3.8e9 work-items) returned wrong maps for keyframe 0 while 1024 keyframes (1.9e9) were right (round 3,
+// tests/test_gpu_fullsize.py::test_config4_full_2048kf_1080p).  Every launch whose grid grows with the number of
+// reference keyframes is therefore issued in slices of reference keyframes: fn(first, count) launches one slice.
+template <typename F>
+void for_ref_slices(int n_ref, long long blocks_per_ref, int threads, F&& fn)
+{
+    const long long max_blocks = (1ll << 30) / threads;
+    const int per = (int)std::max<long long>(1, std::min<long long>(n_ref, max_blocks / std::max<long long>(blocks_per_ref, 1)));
+    for (int first = 0; first < n_ref; first += per) fn(first, std::min(per, n_ref - first));
+}
 
 // HIP events around one stage's launches, on the stream the kernels run on
 struct StageTimer {
@@ -559,6 +579,21 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_act, (size_t)c->P * K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_act_count, (size_t)K))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta_bad, (size_t)K))) return bail(rc);
+    {
+        // a quarter of all pixels, at most 2^20 entries of 16 + 8 n bytes; when it fills up the remaining workgroups
+        // count their open pixels in place (slower, same result)
+        long long cap = std::min<long long>(1ll << 20, std::max<long long>(K1_PX, c->P * K / 4));
+        if (const char* e = getenv("SDM_OPEN_CAPACITY"))  // tests: a tiny list forces the in-place fallback
+            cap = std::max<long long>(K1_PX, std::min<long long>(cap, atoll(e)));
+        c->open_capacity = (unsigned)(cap / K1_PX * K1_PX);
+        if ((rc = dev_alloc(&c->d_open_ctr, 4)) || (rc = dev_alloc(&c->d_open_pix, (size_t)c->open_capacity)) ||
+            (rc = dev_alloc(&c->d_open_vm, (size_t)c->open_capacity)) ||
+            (rc = dev_alloc(&c->d_open_hyp, (size_t)c->open_capacity * cfg->max_neighbours)))
+            return bail(rc);
+        const unsigned init[4] = {0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
+        if (hipMemcpy(c->d_open_ctr, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(SDM_EHIP, "open-list counter initialisation failed"));
+    }
     if ((rc = dev_alloc(&c->d_chunk, (size_t)((c->P + ACT_BLOCK - 1) / ACT_BLOCK)))) return bail(rc);
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
@@ -624,6 +659,10 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_act);
     (void)hipFree(c->d_act_count);
     (void)hipFree(c->d_theta_bad);
+    (void)hipFree(c->d_open_ctr);
+    (void)hipFree(c->d_open_pix);
+    (void)hipFree(c->d_open_vm);
+    (void)hipFree(c->d_open_hyp);
     (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_rgb);
@@ -823,22 +862,47 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     // K1 writes every listed pixel; the rest of the map must be zero (a fresh depth_map_).  It already is
     // when the slot's current map came out of SemiDenseRecon under the same lambdaG.
     if (!all_pipeline_maps(c, n_ref, ref_slots)) {
-        hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
-                           c->d_ref_slots, n_ref);
+        for_ref_slices(n_ref, blocks_for(c->P), BLOCK, [&](int first, int count) {
+            hipLaunchKernelGGL(k_zero_maps, dim3(blocks_for(c->P * count)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                               c->d_ref_slots + first, count);
+        });
         HIP_TRY(hipGetLastError());
     }
-    StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);  // brackets exactly one k_search_fuse launch
+    StageTimer tm(c, SDM_STAGE_SEARCH_FUSE);  // brackets one k_search_fuse launch and its k_fuse_open
     int max_chunks = 0;
     for (int r = 0; r < n_ref; r++) max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + K1_PX - 1) / K1_PX);
     if (max_chunks == 0) return SDM_OK;  // no pixel passes the gradient gate: the maps stay zero
     const size_t lds = k1_lds_bytes(n);
-    const int grid = 8 * ((max_chunks + 7) / 8) * n_ref;
+    const int blocks_per_ref = 8 * ((max_chunks + 7) / 8);
+    OpenList ol;
+    ol.count = c->d_open_ctr + 2 * (c->open_launch & 1u);
+    ol.next = c->d_open_ctr + 2 * ((c->open_launch + 1u) & 1u);
+    ol.capacity = c->open_capacity;
+    ol.pix = c->d_open_pix;
+    ol.vm = c->d_open_vm;
+    ol.hyp = c->d_open_hyp;
+    c->open_launch++;
+    // the pixels the fusion bounds left open, 64 per workgroup; the list length stays on the device (a fixed grid walks
+    // whatever is there, nothing when the list is empty)
+    const size_t lds_open = (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * n + sizeof(unsigned) * (size_t)K1_PX * ((n + 3) / 4);
+    const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, 1024u);
+    // (the slices of one call append to the same open list; k_fuse_open runs once behind the last one)
+    for_ref_slices(n_ref, blocks_per_ref, K1_BLOCK, [&](int first, int count) {
+        if (c->stats_on)
+            hipLaunchKernelGGL(k_search_fuse<true>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
+                               c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
+                               c->d_act, c->pool, c->d_stats, ol);
+        else
+            hipLaunchKernelGGL(k_search_fuse<false>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
+                               c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
+                               c->d_act, c->pool, c->d_stats, ol);
+    });
     if (c->stats_on)
-        hipLaunchKernelGGL(k_search_fuse<true>, dim3(grid), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
-                           c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
+        hipLaunchKernelGGL(k_fuse_open<true>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
+                           c->d_stats);
     else
-        hipLaunchKernelGGL(k_search_fuse<false>, dim3(grid), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P, c->d_refs,
-                           c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats);
+        hipLaunchKernelGGL(k_fuse_open<false>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
+                           c->d_stats);
     HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
@@ -865,16 +929,19 @@ static int launch_intra(sdm_ctx* c, int n_ref, int first, int count, bool check,
 {
     // offsets: [0..K) pool offsets, [K..2K) scratch offsets, [2K..3K) record offsets (in floats)
     const int K = n_ref;  // offset tables are [3][n_ref]
-    const int grid = grid_blocks(c->geom, count);
     if (check) {
-        hipLaunchKernelGGL(k_intra_check, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
-                           c->d_off + first, c->d_off + K + first, count, c->geom);
+        for_ref_slices(count, grid_blocks(c->geom, 1), BLOCK, [&](int f, int cn) {
+            hipLaunchKernelGGL(k_intra_check, dim3(grid_blocks(c->geom, cn)), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
+                               c->d_off + first + f, c->d_off + K + first + f, cn, c->geom);
+        });
         HIP_TRY(hipGetLastError());
     }
     if (grow) {
-        hipLaunchKernelGGL(k_intra_grow, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
-                           c->d_off + K + first, c->d_off + first, (const float*)c->rec, c->d_off + 2 * K + first, 4,
-                           count, c->geom, c->dprm.lambdaG);
+        for_ref_slices(count, grid_blocks(c->geom, 1), BLOCK, [&](int f, int cn) {
+            hipLaunchKernelGGL(k_intra_grow, dim3(grid_blocks(c->geom, cn)), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
+                               c->d_off + K + first + f, c->d_off + first + f, (const float*)c->rec,
+                               c->d_off + 2 * K + first + f, 4, cn, c->geom, c->dprm.lambdaG);
+        });
         HIP_TRY(hipGetLastError());
     }
     return SDM_OK;
@@ -893,15 +960,17 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
         for (int r = 0; r < count; r++)
             max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[first + r]] + BLOCK - 1) / BLOCK);
         if (max_chunks == 0) continue;
-        const int grid = 8 * ((max_chunks + 7) / 8) * count;
+        const int per_ref = 8 * ((max_chunks + 7) / 8);
         if (check) {
             // K2 writes every listed pixel of the scratch planes, and K3's list kernel substitutes zeros for
             // neighbours outside the list instead of reading them, so the planes need no clearing -- unless the
             // pass stands alone and the whole plane is copied back below
             if (!grow) HIP_TRY(hipMemsetAsync(c->scratch, 0, sizeof(float2) * c->P * count, c->stream));
-            hipLaunchKernelGGL(k_intra_list<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
-                               c->d_off, c->d_off + K, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act,
-                               c->rec, c->H, c->dprm.lambdaG);
+            for_ref_slices(count, per_ref, BLOCK, [&](int f, int cn) {
+                hipLaunchKernelGGL(k_intra_list<false>, dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->pool, c->scratch,
+                                   c->d_off, c->d_off + K, c->d_refs, first + f, cn, c->W, max_chunks, c->P, c->d_act, c->rec,
+                                   c->H, c->dprm.lambdaG);
+            });
             HIP_TRY(hipGetLastError());
         } else {
             for (int r = 0; r < count; r++)
@@ -909,9 +978,11 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
                                        sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
         }
         if (grow) {
-            hipLaunchKernelGGL(k_intra_list<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
-                               c->d_off + K, c->d_off, c->d_refs, first, count, c->W, max_chunks, c->P, c->d_act,
-                               c->rec, c->H, c->dprm.lambdaG);
+            for_ref_slices(count, per_ref, BLOCK, [&](int f, int cn) {
+                hipLaunchKernelGGL(k_intra_list<true>, dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->scratch, c->pool,
+                                   c->d_off + K, c->d_off, c->d_refs, first + f, cn, c->W, max_chunks, c->P, c->d_act, c->rec,
+                                   c->H, c->dprm.lambdaG);
+            });
             HIP_TRY(hipGetLastError());
         } else {
             for (int r = 0; r < count; r++)
@@ -1032,8 +1103,10 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
             bool chk_ok = true;  // checked planes already zero outside the lists?
             for (int r = 0; r < n_ref; r++) chk_ok = chk_ok && c->chk_sparse[ref_slots[r]];
             if (!chk_ok) {
-                hipLaunchKernelGGL(k_rho_copy, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
-                                   c->chk, c->P, c->d_ref_slots, n_ref);
+                for_ref_slices(n_ref, blocks_for(c->P), BLOCK, [&](int first, int count) {
+                    hipLaunchKernelGGL(k_rho_copy, dim3(blocks_for(c->P * count)), dim3(BLOCK), 0, c->stream, c->pool, c->chk,
+                                       c->P, c->d_ref_slots + first, count);
+                });
                 HIP_TRY(hipGetLastError());
             }
             for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 1;
@@ -1041,27 +1114,35 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
             bool fuse = want_xyz && c->xyz != nullptr;
             for (int r = 0; r < n_ref && fuse; r++) fuse = c->xyz_sparse[ref_slots[r]] != 0;
             if (max_chunks > 0) {
-                const dim3 grid(8 * ((max_chunks + 7) / 8) * n_ref);
-                if (fuse)
-                    hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P, c->d_refs,
-                                       c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm.lambdaN, c->d_act, c->chk,
-                                       c->d_meta, c->xyz);
-                else
-                    hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P, c->d_refs,
-                                       c->d_pairs, n_ref, n, c->W, c->H, max_chunks, c->dprm.lambdaN, c->d_act, c->chk,
-                                       c->d_meta, c->xyz);
+                const int per_ref = 8 * ((max_chunks + 7) / 8);
+                for_ref_slices(n_ref, per_ref, BLOCK, [&](int first, int count) {
+                    const dim3 grid(per_ref * count);
+                    if (fuse)
+                        hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                                           c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
+                                           c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
+                    else
+                        hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                                           c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
+                                           c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
+                });
                 HIP_TRY(hipGetLastError());
             }
             *xyz_done = fuse;
         } else {
             for (int r = 0; r < n_ref; r++) c->chk_sparse[ref_slots[r]] = 0;  // the generic kernel copies arbitrary maps
-            hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, n_ref)), dim3(BLOCK), 0, c->stream, c->pool,
-                               c->P, c->d_refs, c->d_pairs, n_ref, n, c->geom, c->dprm.lambdaN, c->chk);
+            for_ref_slices(n_ref, grid_blocks(c->geom, 1), BLOCK, [&](int first, int count) {
+                hipLaunchKernelGGL(k_inter_check, dim3(grid_blocks(c->geom, count)), dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                                   c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->geom, c->dprm.lambdaN,
+                                   c->chk);
+            });
             HIP_TRY(hipGetLastError());
         }
         if (commit) {
-            hipLaunchKernelGGL(k_commit, dim3(blocks_for(c->P * n_ref)), dim3(BLOCK), 0, c->stream, c->chk, c->pool,
-                               c->P, c->d_ref_slots, n_ref);
+            for_ref_slices(n_ref, blocks_for(c->P), BLOCK, [&](int first, int count) {
+                hipLaunchKernelGGL(k_commit, dim3(blocks_for(c->P * count)), dim3(BLOCK), 0, c->stream, c->chk, c->pool, c->P,
+                                   c->d_ref_slots + first, count);
+            });
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1102,12 +1183,18 @@ int sdm_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int source)
         max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[r]] + BLOCK - 1) / BLOCK);
     }
     if (sparse) {
-        if (max_chunks > 0)
-            hipLaunchKernelGGL(k_pointset_list, dim3(8 * ((max_chunks + 7) / 8) * n_ref), dim3(BLOCK), 0, c->stream, src,
-                               sstride, c->P, c->d_meta, c->d_refs, n_ref, c->W, max_chunks, c->d_act, c->xyz);
+        if (max_chunks > 0) {
+            const int per_ref = 8 * ((max_chunks + 7) / 8);
+            for_ref_slices(n_ref, per_ref, BLOCK, [&](int first, int count) {
+                hipLaunchKernelGGL(k_pointset_list, dim3(per_ref * count), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
+                                   c->d_meta, c->d_refs + first, count, c->W, max_chunks, c->d_act, c->xyz);
+            });
+        }
     } else {
-        hipLaunchKernelGGL(k_pointset, dim3(blocks_for(c->P), n_ref), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
-                           c->d_meta, c->d_ref_slots, n_ref, c->W, c->H, c->xyz);
+        for_ref_slices(n_ref, blocks_for(c->P), BLOCK, [&](int first, int count) {
+            hipLaunchKernelGGL(k_pointset, dim3(blocks_for(c->P), count), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
+                               c->d_meta, c->d_ref_slots + first, count, c->W, c->H, c->xyz);
+        });
         // a full rewrite leaves zeros wherever the source is zero: sparse again iff the source was
         for (int r = 0; r < n_ref; r++)
             c->xyz_sparse[ref_slots[r]] = (c->recon_lambdaG[ref_slots[r]] == c->dprm.lambdaG) &&

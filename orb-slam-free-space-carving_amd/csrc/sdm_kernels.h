@@ -455,16 +455,83 @@ __global__ __launch_bounds__(BLOCK) void k_zero_maps(float2* __restrict__ pool, 
 constexpr int K1_PX = 64;                // active pixels per workgroup
 constexpr int K1_WAVES = SDM_K1_WAVES;   // neighbour stripes
 constexpr int K1_BLOCK = K1_PX * K1_WAVES;
+constexpr int K1_OUTLIER_ROWS = 4;  // rows outside the first hypothesis' set that the fusion bound may still test
 __host__ __device__ inline size_t k1_lds_bytes(int n)
 {
     const size_t nn = (size_t)(n > 0 ? n : 1);
-#if SDM_K1_OPT & 0x100
-    return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
-           sizeof(unsigned long long) * K1_PX + sizeof(unsigned) * K1_PX + sizeof(float) * ((size_t)PCV_FLOATS * nn + 4);
-#else
-    return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * ((nn + 3) / 4) +
-           sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned) * K1_PX;
-#endif
+    // the per-row counters (bytes, 4 rows per word) double as the outlier rows' counters of the fusion bound: at least
+    // K1_OUTLIER_ROWS words per pixel
+    const size_t cw = (nn + 3) / 4 > (size_t)K1_OUTLIER_ROWS ? (nn + 3) / 4 : (size_t)K1_OUTLIER_ROWS;
+    return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * cw +
+           sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned long long) * K1_PX + 16;
+}
+
+// Pixels whose fusion neither bound settles are not finished by their workgroup: they are appended -- hypotheses and all --
+// to a per-launch list, and k_fuse_open runs the all-pairs count for 64 OPEN pixels per workgroup.  A clean workgroup
+// never pays the pair loop because one of its 64 pixels is open.
+struct OpenList {
+    unsigned* count;          // [0] entries reserved by this launch, [1] the first reservation that did not fit (else ~0u):
+                              // reservations are handed out in order, so the entries below min([0], [1]) are exactly the
+                              // ones that were written; a workgroup whose reservation did not fit finished its pixels itself
+    unsigned* next;           // the counter pair of the NEXT launch, reset by k_fuse_open (no memset between launches)
+    unsigned capacity;        // entries the arrays hold (a multiple of 64)
+    long long* pix;           // [capacity] element index into the depth pool
+    unsigned long long* vm;   // [capacity] accepted-hypothesis mask
+    float2* hyp;              // [capacity/64][n][64] {rho, sigma}
+};
+
+// ---- the all-pairs count of InverseDepthHypothesisFusion and the fusion over the winning row (K1 and K1b) -------------------
+// ChiTest is symmetric bit for bit (the squared difference and the float sum of the two quotients commute), so every
+// unordered pair {a,b} is tested once and credited to both rows' set sizes: byte counters in LDS, row a in byte a&3 of word
+// [a>>2][64] (a is wave-uniform, so the shift is a scalar; a 32-bit add of 1 << 8*(a&3) cannot carry over: sizes <= 64).
+// Rows are dealt to the four waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.
+__device__ __forceinline__ void k1_count_all_pairs(const float2* hyp, const float* sgm, unsigned* cnt, unsigned long long vm,
+                                                   int n, int p, int w)
+{
+    for (int i = 0; K1_WAVES * i < n; i++) {
+        const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
+        if (a >= n || !((vm >> a) & 1ull)) continue;
+        const float2 ha = hyp[a * K1_PX + p];
+        const float sa = sgm[a * K1_PX + p];
+        // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
+        unsigned c = (sa * sa > 0.0f) ? 1u : 0u;
+        for (int bb = a + 1; bb < n; bb++) {
+            const float2 hb = hyp[bb * K1_PX + p];
+            if (chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) {
+                c++;
+                atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
+            }
+        }
+        atomicAdd(&cnt[(a >> 2) * K1_PX + p], c << (8 * (a & 3)));
+    }
+}
+// the first row with the largest count (PM.cc:616: strict '>'), its membership re-derived for GetFusion overload B
+// (PM.cc:947-970, hypothesis order); false when that set has fewer than lambdaN members (PM.cc:623)
+__device__ __forceinline__ bool k1_fuse_counted(const float2* hyp, const float* sgm, const unsigned* cnt, unsigned long long vm,
+                                                int n, int p, int lambdaN, float2& result)
+{
+    unsigned best = 0;
+    int besta = 0;
+    for (int a = 0; a < n; a++) {
+        if (!((vm >> a) & 1ull)) continue;
+        const unsigned c = (cnt[(a >> 2) * K1_PX + p] >> (8 * (a & 3))) & 0xffu;
+        if (c > best) {  // first largest set wins
+            best = c;
+            besta = a;
+        }
+    }
+    if ((int)best < lambdaN) return false;  // PM.cc:623
+    const float2 ha = hyp[besta * K1_PX + p];
+    const float sa = sgm[besta * K1_PX + p];
+    float pjsj = 0.f, rsj = 0.f;
+    for (int bb = 0; bb < n; bb++) {
+        if (!((vm >> bb) & 1ull)) continue;
+        const float2 hb = hyp[bb * K1_PX + p];
+        const bool in = (bb == besta) ? (sa * sa > 0.0f) : chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p]);
+        if (in) fusion_accum(hb.x, sgm[bb * K1_PX + p], pjsj, rsj);
+    }
+    result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
+    return true;
 }
 
 // 8 waves per SIMD (64 vector registers): with the search constants in vector registers (SDM_K1_OPT bit 8) hipcc would
@@ -482,7 +549,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
                                                        int W, int H, int max_chunks, DevParams prm,
                                                        const unsigned* __restrict__ act, float2* __restrict__ pool,
-                                                       unsigned long long* __restrict__ stats)
+                                                       unsigned long long* __restrict__ stats, OpenList open_list)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // [n][64] {rho, 1/sigma^2 (NaN = take the exact path)}: all a pair test reads; sigma itself is needed only by
@@ -492,16 +559,10 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     // compatible-set sizes (<= n <= 64), one byte each: row a lives in byte a&3 of word [a>>2][64].  a is
     // wave-uniform, so the shift is a scalar; a 32-bit LDS atomic add of 1<<8*(a&3) cannot carry over.
     unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
-    const int cnt_words = (n + 3) >> 2;
-#if SDM_K1_OPT & 0x100
-    unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [64], OR of the waves' masks
-    unsigned* cnt0 = reinterpret_cast<unsigned*>(pmask + K1_PX);  // [64] size of the FIRST hypothesis' compatible set
-    float* lref = reinterpret_cast<float*>(cnt0 + K1_PX);        // {fx, cx, mind, maxd} + [n][PCV_FLOATS] search constants
-    float* lcv = lref + 4;
-#else
+    const int cnt_words = max((n + 3) >> 2, K1_OUTLIER_ROWS);
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
-    unsigned* cnt0 = reinterpret_cast<unsigned*>(pmask + K1_BLOCK);  // [64] size of the FIRST hypothesis' compatible set
-#endif
+    unsigned long long* set0 = pmask + K1_BLOCK;  // [64] members (other than itself) of the FIRST hypothesis' compatible set
+    unsigned* xbase = reinterpret_cast<unsigned*>(set0 + K1_PX);  // [1] first open-list entry of this workgroup (or ~0u)
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -535,26 +596,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     }
     SearchStats st = {0, 0, 0};
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
-#if SDM_K1_OPT & 0x100
-    if (w == 0) pmask[p] = 0ull;
-    // the searches read their per-pair constants from this LDS copy, i.e. into VECTOR registers: float add / mul with
-    // a scalar-register operand issue at half the rate (sdm_device.h, bit 8)
-    {
-        // 5 x 16 bytes per pair: thread t copies quad t%5 of pair t/5
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(pcs);
-        float4* dst = reinterpret_cast<float4*>(lcv);
-        for (int i = tid; i < n * (PCV_FLOATS / 4); i += K1_BLOCK) {
-            const int j = (i * 205) >> 10;  // i / 5 for i < 1024 (n <= 64 pairs: i < 320)
-            dst[i] = src[j * (int)(sizeof(PairConst) / sizeof(float4)) + (i - 5 * j)];
-        }
-        if (tid < 4) lref[tid] = (tid == 0) ? rc.fx : (tid == 1) ? rc.cx : (tid == 2) ? rc.mind : rc.maxd;
-    }
-    __syncthreads();
-    const float* __restrict__ rcv = lref;
-#else
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
     const float* __restrict__ rcv = rcvb;
-#endif
     // Hypotheses go to LDS in neighbour order.  "No hypothesis" (PM.cc:216) is stored as rho = +Inf,
     // sigma = 1: against any real hypothesis the squared difference is +Inf, so the compatibility
     // test fails on its fast path and the pair loops need no validity checks.  Each wave also keeps
@@ -566,11 +609,7 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         float2 h = make_float2(__builtin_inff(), 1.0f);
         if (on) {
             float rho, sigma, bu, bv;
-#if SDM_K1_OPT & 0x100
-            const float* __restrict__ cv = lcv + j * PCV_FLOATS;
-#else
             const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
-#endif
             bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
                                              sigma, bu, bv, &st);
             if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
@@ -582,27 +621,15 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         sgm[j * K1_PX + p] = h.y;
     }
     for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
-    if (w == 0) cnt0[p] = 0u;
-#if SDM_K1_OPT & 0x100
-    if (mymask) atomicOr(&pmask[p], mymask);
-#else
+    if (w == 0) set0[p] = 0ull;
     pmask[tid] = mymask;
-#endif
     __syncthreads();
 
-    // InverseDepthHypothesisFusion, PM.cc:598-626.  ChiTest is symmetric bit for bit (the squared
-    // difference and the float sum of the two quotients commute), so every unordered pair {a,b} is
-    // tested once and credited to both rows' set sizes (LDS counters).  Rows are dealt to the four
-    // waves in a zig-zag (w, 7-w, 8+w, 15-w, ...) that balances the triangular pair counts.  Wave 0
-    // then takes the first row with the largest count (PM.cc:616: strict '>') and re-derives only
-    // that row's membership for the fusion sum.
-#if SDM_K1_OPT & 0x100
-    const unsigned long long vm = pmask[p];
-#else
+    // InverseDepthHypothesisFusion, PM.cc:598-626: the first hypothesis whose compatible set is largest (strict '>',
+    // PM.cc:616), then GetFusion over that set.
     unsigned long long vm = 0;
 #pragma unroll
     for (int q = 0; q < K1_WAVES; q++) vm |= pmask[q * K1_PX + p];
-#endif
 #if SDM_ABLATE == 1
     const int nh = 0;
     if (vm == 0x123456789ull) pool[0] = make_float2(1.f, 1.f);
@@ -610,89 +637,123 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     const int nh = __popcll(vm);
 #endif
     const bool go = nh > prm.lambdaN;  // PM.cc:221
-    // Branch-and-bound on "the first largest compatible set" (PM.cc:616, strict '>'): a set holds at most the nh
-    // accepted hypotheses, so when the FIRST hypothesis a0 is compatible with all the others its set (size nh) is
-    // the first largest one and no other row needs testing -- nh-1 tests instead of nh(nh-1)/2.  The waves share
-    // row a0's tests (b = w, w+4, ...); pixels it does not settle take the full pair loop below.
+    // Branch-and-bound.  Let a0 be the FIRST accepted hypothesis, S0 its compatible set and O the accepted hypotheses
+    // outside S0.  No row precedes a0, so S0 is the answer iff no row has a LARGER set:
+    //  (1) O empty: a set holds at most the nh accepted hypotheses, so |S0| = nh is maximal -- nh-1 tests instead of
+    //      nh(nh-1)/2;
+    //  (2) O small: a row b in S0 can only exceed |S0| by being compatible with some o in O, so it suffices to test the
+    //      rows o in O against everything: if no o is compatible with a member of S0 (then |set(b)| <= |S0| for every b in
+    //      S0) and no o's own set is larger than S0, S0 stands -- (1 + |O|) rows instead of nh.
+    // The four waves share each row's tests (b = w, w+4, ...).  Pixels neither case settles are handed to k_fuse_open
+    // (the all-pairs count with 64 open pixels per workgroup); only when that list is full does this workgroup run the
+    // pair loop itself.
     const int a0 = (int)__ffsll((long long)vm) - 1;  // first accepted hypothesis (-1 if none)
     bool self0 = false;
     if (go) {
         const float2 ha = hyp[a0 * K1_PX + p];
         const float sa = sgm[a0 * K1_PX + p];
         self0 = sa * sa > 0.0f;  // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
-        unsigned c = 0;
+        unsigned long long m = 0;
         for (int bb = w; bb < n; bb += K1_WAVES) {
             const float2 hb = hyp[bb * K1_PX + p];  // "no hypothesis" rows hold rho = +Inf: never compatible
-            if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) c++;
+            if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) m |= 1ull << bb;
         }
-        if (c) atomicAdd(&cnt0[p], c);
+        if (m) atomicOr(&set0[p], m);
     }
     __syncthreads();
-#if SDM_ABLATE == 9  // diagnostic build: never take the shortcut (every fusing pixel runs the all-pairs count)
-    const bool settled = false;
+    const unsigned long long S0 = go ? (set0[p] | (self0 ? (1ull << a0) : 0ull)) : 0ull;
+    const int s0 = __popcll(S0);
+#if SDM_ABLATE == 9  // diagnostic build: never take a shortcut (every fusing pixel runs the all-pairs count)
+    bool settled = false;
+    const bool few = false;
 #else
-    const bool settled = go && self0 && (int)cnt0[p] + 1 == nh;
-#endif
-    // lanes are pixels in every wave, so this is the same value in all four waves: a uniform branch around the pair loop
-    const bool any_open = __builtin_amdgcn_ballot_w64(go && !settled) != 0ull;
-    if (any_open) {
-        if (go && !settled) {
-            for (int i = 0; K1_WAVES * i < n; i++) {
-                const int a = K1_WAVES * i + ((i & 1) ? (K1_WAVES - 1 - w) : w);
-                if (a >= n || !((vm >> a) & 1ull)) continue;
-                const float2 ha = hyp[a * K1_PX + p];
-                const float sa = sgm[a * K1_PX + p];
-                // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
-                unsigned c = (sa * sa > 0.0f) ? 1u : 0u;
-                for (int bb = a + 1; bb < n; bb++) {
+    bool settled = go && self0 && s0 == nh;  // case (1)
+    const unsigned long long O = vm & ~S0;
+    // case (2) candidates: a0 compatible with itself, at most K1_OUTLIER_ROWS rows outside its set
+    const bool few = go && !settled && self0 && __popcll(O) <= K1_OUTLIER_ROWS;
+    // lanes are pixels in every wave, so the ballots below have the same value in all four waves: uniform branches
+    if (__builtin_amdgcn_ballot_w64(few) != 0ull) {
+        unsigned* orow = cnt;  // [K1_OUTLIER_ROWS][64]: set size of the i-th outlier row, + 0x10000 per member of S0 it is
+                               // compatible with (the pair loop's counters are not in use yet; re-zeroed below)
+        unsigned long long rem = few ? O : 0ull;
+        for (int i = 0; i < K1_OUTLIER_ROWS && __builtin_amdgcn_ballot_w64(rem != 0ull) != 0ull; i++) {
+            if (rem != 0ull) {
+                const int o = (int)__ffsll((long long)rem) - 1;
+                rem &= rem - 1ull;
+                const float2 ho = hyp[o * K1_PX + p];
+                const float so = sgm[o * K1_PX + p];
+                unsigned c = (w == 0 && so * so > 0.0f) ? 1u : 0u;  // its self pair, counted once
+                for (int bb = w; bb < n; bb += K1_WAVES) {
                     const float2 hb = hyp[bb * K1_PX + p];
-                    if (chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) {
-                        c++;
-                        atomicAdd(&cnt[(bb >> 2) * K1_PX + p], 1u << (8 * (bb & 3)));
-                    }
+                    if (bb != o && chi_test_lazy(ho, hb, so, &sgm[bb * K1_PX + p])) c += ((S0 >> bb) & 1ull) ? 0x10001u : 1u;
                 }
-                atomicAdd(&cnt[(a >> 2) * K1_PX + p], c << (8 * (a & 3)));
+                if (c) atomicAdd(&orow[i * K1_PX + p], c);
             }
         }
         __syncthreads();
+        if (few) {
+            bool stands = true;
+            const int nO = __popcll(O);
+            for (int i = 0; i < K1_OUTLIER_ROWS; i++) {
+                const unsigned v = orow[i * K1_PX + p];
+                if (i < nO) stands = stands && (v >> 16) == 0u && (int)(v & 0xffffu) <= s0;
+            }
+            settled = stands;
+        }
+        __syncthreads();  // every wave has read its rows before they become the pair loop's counters again
+        for (int q = w; q < K1_OUTLIER_ROWS; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
+    }
+#endif
+    // ---- pixels still open: defer them to k_fuse_open, or (list full) count all pairs here
+    const bool open = go && !settled;
+    const unsigned long long open_mask = __builtin_amdgcn_ballot_w64(open);  // the same in all four waves
+    bool deferred = false;
+    if (open_mask != 0ull) {
+        if (tid == 0) {
+            const unsigned cntw = (unsigned)__popcll(open_mask);
+            const unsigned base = atomicAdd(&open_list.count[0], cntw);
+            const bool fits = base + cntw <= open_list.capacity;
+            if (!fits) atomicMin(&open_list.count[1], base);
+            xbase[0] = fits ? base : 0xFFFFFFFFu;
+        }
+        __syncthreads();  // also orders the counter re-zeroing above before the pair loop below
+        const unsigned base = xbase[0];
+        deferred = base != 0xFFFFFFFFu;
+        if (deferred) {
+            if (open) {
+                // entry e of the list lives in block e/64, lane e%64: [block][hypothesis][lane] keeps k_fuse_open's loads
+                // coalesced.  The four waves share the rows.
+                const unsigned e = base + (unsigned)__popcll(open_mask & ((1ull << p) - 1ull));
+                float2* __restrict__ dst = open_list.hyp + ((size_t)(e >> 6) * n) * K1_PX + (e & 63u);
+                for (int j = w; j < n; j += K1_WAVES) dst[(size_t)j * K1_PX] = make_float2(hyp[j * K1_PX + p].x, sgm[j * K1_PX + p]);
+                if (w == 0) {
+                    open_list.pix[e] = (long long)rc.slot * plane + y * W + x;
+                    open_list.vm[e] = vm;
+                }
+            }
+        } else {
+            if (open) k1_count_all_pairs(hyp, sgm, cnt, vm, n, p, w);
+            __syncthreads();
+        }
     }
 
     unsigned long long n_fused = 0;
-    if (w == 0 && on) {
+    if (w == 0 && on && !(open && deferred)) {
         float2 result = make_float2(0.f, 0.f);  // a fresh depth_map_/depth_sigma_ entry (not fused)
         if (settled) {
-            // the first hypothesis' set is every accepted hypothesis: GetFusion overload B over them, in order, PM.cc:947-970
-            float pjsj = 0.f, rsj = 0.f;
-            for (int bb = 0; bb < n; bb++) {
-                if (!((vm >> bb) & 1ull)) continue;
-                fusion_accum(hyp[bb * K1_PX + p].x, sgm[bb * K1_PX + p], pjsj, rsj);
-            }
-            result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
-            n_fused = 1;
-        } else if (go) {
-            unsigned best = 0;
-            int besta = 0;
-            for (int a = 0; a < n; a++) {
-                if (!((vm >> a) & 1ull)) continue;
-                const unsigned c = (cnt[(a >> 2) * K1_PX + p] >> (8 * (a & 3))) & 0xffu;
-                if (c > best) {  // first largest set wins
-                    best = c;
-                    besta = a;
-                }
-            }
-            if ((int)best >= prm.lambdaN) {  // PM.cc:623
-                const float2 ha = hyp[besta * K1_PX + p];
-                const float sa = sgm[besta * K1_PX + p];
-                float pjsj = 0.f, rsj = 0.f;  // GetFusion overload B over the set, in hypothesis order, PM.cc:947-970
+            // the first hypothesis' set S0 stands (PM.cc:623 still asks for lambdaN members): GetFusion overload B over its
+            // members, in hypothesis order, PM.cc:947-970
+            if (s0 >= prm.lambdaN) {
+                float pjsj = 0.f, rsj = 0.f;
                 for (int bb = 0; bb < n; bb++) {
-                    if (!((vm >> bb) & 1ull)) continue;
-                    const float2 hb = hyp[bb * K1_PX + p];
-                    const bool in = (bb == besta) ? (sa * sa > 0.0f) : chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p]);
-                    if (in) fusion_accum(hb.x, sgm[bb * K1_PX + p], pjsj, rsj);
+                    if (!((S0 >> bb) & 1ull)) continue;
+                    fusion_accum(hyp[bb * K1_PX + p].x, sgm[bb * K1_PX + p], pjsj, rsj);
                 }
                 result = make_float2(pjsj / rsj, sqrtf(1 / rsj));  // PM.cc:225-226
                 n_fused = 1;
             }
+        } else if (go) {
+            n_fused = k1_fuse_counted(hyp, sgm, cnt, vm, n, p, prm.lambdaN, result) ? 1 : 0;
         }
         // every listed pixel is written (fused value or zero); pixels outside the list are zero already
         pool[(long long)rc.slot * plane + y * W + x] = result;
@@ -706,6 +767,53 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
             if ((tid & 63) == 0 && s) atomicAdd(&stats[k], s);
         }
+    }
+}
+
+// ---- K1b: the all-pairs count for the pixels K1 left open, 64 of them per workgroup ---------------------------------------
+// Grid-stride over the blocks of the launch's open list (the entry count lives on the device: no host read-back).  Same
+// LDS layout and the same counting / fusion code as K1's in-place fallback, so the result is the same bit for bit.
+template <bool STATS>
+__global__ __launch_bounds__(K1_BLOCK) void k_fuse_open(OpenList open_list, int n, DevParams prm, float2* __restrict__ pool,
+                                                        unsigned long long* __restrict__ stats)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float2* hyp = reinterpret_cast<float2*>(smem_raw);               // [n][64] {rho, 1/sigma^2}
+    float* sgm = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] sigma
+    unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
+    const int cnt_words = (n + 3) >> 2;
+    const unsigned total = min(open_list.count[0], open_list.count[1]);
+    const int tid = threadIdx.x, p = tid & (K1_PX - 1);
+    if (blockIdx.x == 0 && tid == 0) {  // the next launch's pair: nobody uses it before this kernel has finished
+        open_list.next[0] = 0u;
+        open_list.next[1] = 0xFFFFFFFFu;
+    }
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long n_fused = 0;
+    for (unsigned blk = blockIdx.x; blk * (unsigned)K1_PX < total; blk += gridDim.x) {
+        const unsigned e = blk * K1_PX + p;
+        const bool on = e < total;
+        const float2* __restrict__ src = open_list.hyp + ((size_t)blk * n) * K1_PX + p;
+        for (int j = w; j < n; j += K1_WAVES) {
+            const float2 h = on ? src[(size_t)j * K1_PX] : make_float2(__builtin_inff(), 1.0f);
+            hyp[j * K1_PX + p] = make_float2(h.x, safe_rcp_sq(h.y));
+            sgm[j * K1_PX + p] = h.y;
+        }
+        for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
+        const unsigned long long vm = on ? open_list.vm[e] : 0ull;
+        __syncthreads();
+        if (on) k1_count_all_pairs(hyp, sgm, cnt, vm, n, p, w);
+        __syncthreads();
+        if (w == 0 && on) {
+            float2 result = make_float2(0.f, 0.f);
+            if (k1_fuse_counted(hyp, sgm, cnt, vm, n, p, prm.lambdaN, result)) n_fused++;
+            pool[open_list.pix[e]] = result;
+        }
+        __syncthreads();  // the LDS block is reused by the next list block
+    }
+    if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) n_fused += __shfl_down(n_fused, o);
+        if ((tid & 63) == 0 && n_fused) atomicAdd(&stats[4], n_fused);
     }
 }
 

@@ -6,7 +6,8 @@
 // what would go into the CARV transcript (SFMTranscriptInterface_ORBSLAM.cpp:319-374).  tests/test_gpu_queue.py replays
 // the same schedule on the CPU oracle and compares every injected point bit for bit.
 //
-// usage: test_semi_dense_queue_gpu IN.bin OUT.bin    (IN: the blob of tests/test_gpu_cpp_class.py::write_blob)
+// usage: test_semi_dense_queue_gpu IN.bin OUT.bin [MAX_SIGMA]   (IN: the blob of tests/test_gpu_cpp_class.py::write_blob;
+//        MAX_SIGMA: the injection filter, default the obj writer's 0.01, PM.cc:120)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -104,7 +105,8 @@ int main(int argc, char** argv)
             fwrite(p, sizeof(float), 3, o);
         }
     };
-    sdm_adapter::SemiDenseQueue q(&pm, &map, image, inject, /*max_queue=*/(size_t)n_kf);
+    const double max_sigma = argc > 3 ? atof(argv[3]) : 0.01;
+    sdm_adapter::SemiDenseQueue q(&pm, &map, image, inject, /*max_queue=*/(size_t)n_kf, max_sigma);
     for (int k = 0; k < n_kf; k++) q.Enqueue(&kfs[k]);  // LocalMapping thread, creation order
     int processed = 0;
     while (q.ProcessOne()) processed++;                  // Modeler thread's idle branch
