@@ -1181,16 +1181,24 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
     const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
     const float denom2 = depthp * pc->tz;
     const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
-    const bool valid = (xj >= 0 && xj < colsm1 && yj >= 0 && yj < rowsm1);  // PM.cc:695
-    // lanes that project outside fetch pixel (0,0): the loads stay unconditional, their taps never count
-    const int x0 = valid ? (int)floorf(xj) : 0, y0 = valid ? (int)floorf(yj) : 0;
-    const Row2 ra = *reinterpret_cast<const Row2*>(nb + y0 * W + x0);
-    const Row2 rb = *reinterpret_cast<const Row2*>(nb + (y0 + 1) * W + x0);
+    // PM.cc:695: 0 <= xj < cols-1 and 0 <= yj < rows-1 as ONE unsigned comparison per coordinate: x + 0.0f turns a -0
+    // (which passes "x >= 0") into +0, a non-negative float orders like its bit pattern, negative values and NaN land
+    // above every bound
+    const unsigned bx = __float_as_uint(xj + 0.0f), by = __float_as_uint(yj + 0.0f);
+    const bool valid = (bx < __float_as_uint(colsm1)) & (by < __float_as_uint(rowsm1));
+    // (int)xj truncates, which is floor for the valid (non-negative) coordinates; lanes that project outside fetch
+    // pixel (0,0): the loads stay unconditional, their taps never count.  Byte offsets from the neighbour's plane
+    // (8 bytes per pixel, < 2^30) keep the address arithmetic in 32 bits: one 24-bit multiply-add and a shift.
+    unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
+    off = valid ? off : 0u;
+    const char* __restrict__ nbb = reinterpret_cast<const char*>(nb);
+    const Row2 ra = *reinterpret_cast<const Row2*>(nbb + off);
+    const Row2 rb = *reinterpret_cast<const Row2*>(nbb + (size_t)W * 8 + off);
     const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
     const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
     const float lim = valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
     float nsJr = in.sum_Jr, nsJJ = in.sum_JJ;
-    int nj = 0;
+    float njf = 0.0f;
     unsigned amb = 0;
     // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
     // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator and the
@@ -1217,23 +1225,27 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
         const float d2sigma = djn * djn * sg;
         const float rd = rcp_fast(d2sigma);
         const float J = quot_fast(-rzxp, d2sigma, rd);  // PM.cc:782
-        float rnum = djn - dp * rzxp - pc->tz;        // PM.cc:783
+        float rnum = djn - dp * rzxp - pc->tz;          // PM.cc:783
         rnum = c ? rnum : 1.0f;
         const float r0 = quot_fast(rnum, d2sigma, rd);
         rn[k] = rnum;
         d2s[k] = d2sigma;
-        const float aJr = nsJr + J * r0, aJJ = nsJJ + J * J;
-        nsJr = c ? aJr : nsJr;
-        nsJJ = c ? aJJ : nsJJ;
-        nj += c ? 1 : 0;
+        // a tap that does not count adds (finite) * 0 = +-0 to sums that are never -0 (they start at +0): the sums are the
+        // reference's, and one select (the 0/1 weight) replaces three.  Finite: its operands are 1.0f or inside the tap
+        // window, so |J| <= |rzxp| 2^39 and |r0| <= 2^39, and |rzxp| < 2^20 is part of the slow flag below.
+        const float wgt = c ? 1.0f : 0.0f;
+        nsJr = nsJr + (J * r0) * wgt;
+        nsJJ = nsJJ + (J * J) * wgt;
+        njf += wgt;
     }
+    const int nj = (njf > 0.0f) ? 1 : 0;
     guard2(g, rn[0], rn[1]);
     guard2(g, rn[2], rn[3]);
     g.ones = umin3(g.ones, (__float_as_uint(d2s[0]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[1]) | 0xFF800000u) + 1u);
     g.ones = umin3(g.ones, (__float_as_uint(d2s[2]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[3]) | 0xFF800000u) + 1u);
     *slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u) | (t_lo < K4_TAP_LO) |
-            (t_hi > K4_TAP_HI);
-    return K4Sums{in.kf_count + ((nj >= 1) ? 1 : 0), nsJr, nsJJ};  // PM.cc:755
+            (t_hi > K4_TAP_HI) | (absbits(rzxp) >= 0x49800000u /* 2^20 */);
+    return K4Sums{in.kf_count + nj, nsJr, nsJJ};  // PM.cc:755
 }
 
 __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
