@@ -70,6 +70,7 @@ struct sdm_ctx {
     float2* d_open_hyp = nullptr;
     unsigned open_capacity = 0;
     unsigned open_launch = 0;
+    unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
     bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
@@ -84,7 +85,13 @@ struct sdm_ctx {
     bool stage_busy[2] = {false, false};
     int stage_next = 0;
     uint8_t* d_im = nullptr;
-    uint8_t *d_rgb = nullptr, *h_rgb = nullptr;  // 4P-byte staging for colour frames (sdm_upload_image_rgb), lazily
+    // colour frames (sdm_upload_image_rgb), allocated on first use: a two-deep pinned ring like the gray path's and one
+    // 4P-byte device buffer (the ingest kernel that reads it is stream-ordered before the next frame's copy)
+    uint8_t* d_rgb = nullptr;
+    uint8_t* h_rgb[2] = {nullptr, nullptr};
+    hipEvent_t rgb_done[2] = {nullptr, nullptr};
+    bool rgb_busy[2] = {false, false};
+    int rgb_next = 0;
     float* d_grad = nullptr;
     float* d_theta = nullptr;
     unsigned long long* d_sums = nullptr;
@@ -583,6 +590,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         // a quarter of all pixels, at most 2^20 entries of 16 + 8 n bytes; when it fills up the remaining workgroups
         // count their open pixels in place (slower, same result)
         long long cap = std::min<long long>(1ll << 20, std::max<long long>(K1_PX, c->P * K / 4));
+        if (const char* e = getenv("SDM_K4_PAD")) c->k4_lds_pad = (unsigned)atoi(e);
         if (const char* e = getenv("SDM_OPEN_CAPACITY"))  // tests: a tiny list forces the in-place fallback
             cap = std::max<long long>(K1_PX, std::min<long long>(cap, atoll(e)));
         c->open_capacity = (unsigned)(cap / K1_PX * K1_PX);
@@ -666,7 +674,10 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_rgb);
-    (void)hipHostFree(c->h_rgb);
+    for (int b = 0; b < 2; b++) {
+        (void)hipHostFree(c->h_rgb[b]);
+        if (c->rgb_done[b]) (void)hipEventDestroy(c->rgb_done[b]);
+    }
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
     (void)hipFree(c->d_sums);
@@ -796,13 +807,26 @@ int sdm_upload_image_rgb(sdm_ctx* c, int slot, const uint8_t* pixels, int order,
     if (dist && !(K[0] != 0.0f && K[1] != 0.0f)) return fail(SDM_EINVAL, "zero focal length");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (!c->d_rgb) {
-        if ((rc = dev_alloc(&c->d_rgb, (size_t)c->P * 4)) || (rc = host_alloc(&c->h_rgb, (size_t)c->P * 4))) return rc;
+        if ((rc = dev_alloc(&c->d_rgb, (size_t)c->P * 4))) return rc;
+        for (int b = 0; b < 2; b++) {
+            if ((rc = host_alloc(&c->h_rgb[b], (size_t)c->P * 4))) return rc;
+            HIP_TRY(hipEventCreateWithFlags(&c->rgb_done[b], hipEventDisableTiming));
+        }
     }
     if ((rc = reset_slot(c, slot))) return rc;
     const size_t bytes = (size_t)c->P * q.channels;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // one pinned colour buffer: the previous frame must have left it
-    memcpy(c->h_rgb, pixels, bytes);
-    HIP_TRY(hipMemcpyAsync(c->d_rgb, c->h_rgb, bytes, hipMemcpyHostToDevice, c->stream));
+    // asynchronous like sdm_upload_image: the frame is copied into a pinned ring buffer (the caller's buffer is free on
+    // return); the host waits only when both ring buffers are still in flight
+    const int b = c->rgb_next;
+    c->rgb_next ^= 1;
+    if (c->rgb_busy[b]) {
+        HIP_TRY(hipEventSynchronize(c->rgb_done[b]));
+        c->rgb_busy[b] = false;
+    }
+    memcpy(c->h_rgb[b], pixels, bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_rgb, c->h_rgb[b], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->rgb_done[b], c->stream));
+    c->rgb_busy[b] = true;
     hipLaunchKernelGGL(k_ingest, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->d_rgb, c->W, c->H, q, c->d_im);
     HIP_TRY(hipGetLastError());
     KfMeta& m = c->h_meta[slot];
@@ -1118,11 +1142,11 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
                 for_ref_slices(n_ref, per_ref, BLOCK, [&](int first, int count) {
                     const dim3 grid(per_ref * count);
                     if (fuse)
-                        hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                        hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
                                            c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
                                            c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
                     else
-                        hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), 0, c->stream, c->pool, c->P,
+                        hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
                                            c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
                                            c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
                 });

@@ -326,18 +326,31 @@ void ProbabilityMapping::UpdateAllSemiDensePointSet()
     }
 }
 
-// PM.cc:385-465.  `pixel`, `F12` and `th_pi` are, at the reference's only call site (PM.cc:213-214),
-// im_(y,x), ComputeFundamental(kf1,kf2) and GradTheta(y,x) of the same keyframes; the engine derives
-// them from the resident keyframes, so the arguments are accepted for signature parity only.
+// PM.cc:385-465.  `pixel`, `F12` and `th_pi` are, at the reference's only call site (PM.cc:213-214), im_(y,x),
+// ComputeFundamental(kf1,kf2) and GradTheta(y,x) of the same keyframes.  The engine derives all three from the resident
+// keyframes, so a caller must pass exactly those: the arguments are CHECKED against the resident values and a mismatch is
+// reported on cerr (the search then still runs on the resident values -- it cannot do anything else -- so the caller knows
+// the answer is not the one the reference would give for its arguments).
 void ProbabilityMapping::EpipolarSearch(sdm::KeyFrame* kf1, sdm::KeyFrame* kf2, const int x, const int y, float pixel,
                                         float min_depth, float max_depth, depthHo* dh, const float F12[9],
                                         float& best_u, float& best_v, float th_pi, float rot)
 {
-    (void)pixel;
-    (void)F12;
-    (void)th_pi;
     const int s1 = SlotOf(kf1), s2 = SlotOf(kf2);
     if (s1 < 0 || s2 < 0 || !dh) return;
+    if (x >= 0 && y >= 0 && x < kf1->im_.cols && y < kf1->im_.rows) {
+        const char* what = nullptr;
+        if (pixel != (float)kf1->im_.at(y, x)) what = "pixel != kf1->im_(y,x)";
+        if (!kf1->GradTheta.empty() && th_pi != kf1->GradTheta.at(y, x)) what = "th_pi != kf1->GradTheta(y,x)";
+        if (F12) {
+            float F[9];
+            if (sdm_pair_geometry(ctx_, s1, s2, F, nullptr, nullptr) == SDM_OK && memcmp(F, F12, sizeof(F)) != 0)
+                what = "F12 != ComputeFundamental(kf1, kf2)";
+        }
+        if (what)
+            std::cerr << "ProbabilityMapping::EpipolarSearch: " << what << " -- the engine searches with the resident "
+                      << "keyframes' values (PM.cc:213-214 passes exactly those); this call's result differs from the "
+                      << "reference's for the given arguments" << std::endl;
+    }
     float out[5];
     if (sdm_epipolar_search(ctx_, s1, s2, x, y, min_depth, max_depth, rot, out) != SDM_OK) {
         report("EpipolarSearch");

@@ -85,6 +85,12 @@ int main(int argc, char** argv)
             px_out.push_back(dh.supported ? 1.f : 0.f);
             px_out.push_back(bu);
         }
+    {   // arguments that are not the resident keyframes' values are reported (once here), not silently ignored
+        ProbabilityMapping::depthHo dh;
+        float bu = 0, bv = 0;
+        pm.EpipolarSearch(&kfs[1], &kfs[2], 9, 7, (float)kfs[1].im_.at(7, 9) + 1.0f, mn, mx, &dh, F, bu, bv,
+                          kfs[1].GradTheta.at(7, 9), 0.0f);
+    }
     std::vector<ProbabilityMapping::depthHo> hs(5);
     for (int i = 0; i < 5; i++) {
         hs[i].depth = 1.0f + 0.01f * i;

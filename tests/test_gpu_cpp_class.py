@@ -71,7 +71,13 @@ def test_cpp_class_matches_oracle_schedule(pkg, oracle, gpu_ok, tmp_path, n_kf, 
     out = tmp_path / "out.bin"
     obj = tmp_path / "cloud.obj"
     tr = tmp_path / "transcript.txt"
-    subprocess.check_call([exe, str(blob), str(out), str(obj), str(tr)], env=dict(os.environ, SDM_TEST_MAX_KF=str(max_kf)))
+    r = subprocess.run([exe, str(blob), str(out), str(obj), str(tr)], env=dict(os.environ, SDM_TEST_MAX_KF=str(max_kf)),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # EpipolarSearch checks pixel / F12 / th_pi against the resident keyframes: the driver passes consistent values in
+    # its sweep (no report) and one deliberately wrong pixel value (one report)
+    assert r.stderr.count("ProbabilityMapping::EpipolarSearch: pixel != kf1->im_(y,x)") == 1, r.stderr[-2000:]
+    assert r.stderr.count("ProbabilityMapping::EpipolarSearch:") == 1, r.stderr[-2000:]
 
     # ---- the same schedule on the oracle ----------------------------------------------------------
     nbrs, bounds, rho, sig, xyz, semi, inter = oracle_schedule(oracle, seq, n_kf, n, depths)
