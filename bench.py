@@ -52,10 +52,12 @@ def parse():
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
-    ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather"],
-                    help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: the "
-                         "all-gather BASELINE.json names (pipelined in sub-blocks behind the reconstruction), or the halo "
-                         "point-to-point form (the other one is timed too: exchange_ms_per_step, value_<other>)")
+    ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather", "allgather_full"],
+                    help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: "
+                         "allgather = RCCL all-gather of the maps that cross ranks (every rank's boundary keyframes, "
+                         "overlapped with the reconstruction of the interior ones); allgather_full = every rank's whole "
+                         "block, pipelined in sub-blocks (BASELINE.json's literal wording, 3x the bytes); halo = "
+                         "point-to-point.  The other forms are timed too: exchange_ms_per_step, value_<form>")
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="N>1: RCCL called by the engine's C ABI (sdm_exchange_*) or torch.distributed on the pool tensor")
     ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (SURVEY.md §8d adversarial set)")
@@ -383,6 +385,7 @@ def main():
             pkg.shard.setup_native_comm(eng)
             wl.step("halo", "native")
             wl.step("allgather", "native")
+            wl.step("allgather_full", "native")
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 -- reported, never swallowed
             ok, why = 0, repr(e)
@@ -422,12 +425,15 @@ def main():
 
     dt, timing, dt_cold, timing_cold, n_prewarm = measure(wl, args.steps, args.warmup, barrier, args.exchange, transport,
                                                           reduce_max if world > 1 else None)
-    exchange_ms, other, dt2 = None, None, None
-    if exchanging:  # the other exchange form, same K steps, so the line carries both
-        other = "allgather" if args.exchange == "halo" else "halo"
-        dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
-        dt2 = reduce_max(dt2)
-        exchange_ms = {args.exchange: round(dt / args.steps * 1e3, 4), other: round(dt2 / args.steps * 1e3, 4)}
+    exchange_ms, others = None, {}
+    if exchanging:  # the other exchange forms, same K steps, so the line carries all three
+        exchange_ms = {args.exchange: round(dt / args.steps * 1e3, 4)}
+        for other in ("allgather", "allgather_full", "halo"):
+            if other == args.exchange:
+                continue
+            dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
+            others[other] = reduce_max(dt2)
+            exchange_ms[other] = round(others[other] / args.steps * 1e3, 4)
 
     if rank != 0:
         eng.close()
@@ -446,8 +452,10 @@ def main():
     if not exchanging:
         xdesc = "no exchange (%s)" % ("1 GPU" if world == 1 else "independent sequences")
     else:
-        xdesc = "%s exchange of {rho,sigma} maps over RCCL (%s)" % (
-            args.exchange, "engine C ABI sdm_exchange_*" if transport == "native" else "torch.distributed")
+        xdesc = "%s of {rho,sigma} maps over RCCL (%s)" % (
+            {"allgather": "all-gather of the boundary keyframes' maps (the ones other ranks read)",
+             "allgather_full": "all-gather of every rank's whole block", "halo": "point-to-point halo exchange"}[args.exchange],
+            "engine C ABI sdm_allgather_* / sdm_exchange_*" if transport == "native" else "torch.distributed")
     out = {
         "metric": "Mpix*KF/s fused (%dx%dxN_KF)" % (W, H),
         "value": round(value, 2),
@@ -482,8 +490,12 @@ def main():
     }
     if exchange_ms:
         out["exchange_ms_per_step"] = exchange_ms
-        out["value_" + other] = round(P * n_total * args.steps / dt2 / 1e6, 2)
-        out["config"]["allgather_pieces"] = pkg.shard.AG_PIECES if transport == "native" else 1
+        for other, dt2 in others.items():
+            out["value_" + other] = round(P * n_total * args.steps / dt2 / 1e6, 2)
+        out["config"]["allgather_full_pieces"] = pkg.shard.AG_PIECES if transport == "native" else 1
+        out["config"]["exchange_maps_per_rank"] = {  # maps every rank RECEIVES per step
+            "allgather": (world - 1) * pl["contrib_count"], "allgather_full": (world - 1) * pl["count"],
+            "halo": sum(len(v) for v in pl["recv"].values())}
     if transport_note:
         out["transport_note"] = transport_note
     if rehearse:

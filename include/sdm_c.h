@@ -192,14 +192,16 @@ int sdm_exchange_halo(sdm_ctx *ctx, int n_send, const int *send_peer, const int 
  * slot dst_slot[i].  Stream-ordered; no host wait. */
 int sdm_allgather_depth(sdm_ctx *ctx, int first_slot, int count, int n_fetch, const int *fetch_index,
                         const int *dst_slot);
-/* The same all-gather in pieces, overlapped with the reconstruction: _begin names this rank's block (local slots
- * first_slot .. first_slot+block_count-1); each _piece(offset, count) -- in block order, covering it exactly -- is
- * called right after the sdm_recon of those keyframes and gathers them on a second stream behind an event, so the
- * next sub-block's sdm_recon overlaps the transfer; _finish orders later work (sdm_inter_check) behind the last
- * piece and copies the maps this rank reads (fetch_index = owner_rank*block_count + position) into dst_slot.
+/* The all-gather in pieces, overlapped with the reconstruction.  Every rank contributes maps_per_rank maps (the
+ * same number on all ranks) in one or more pieces: _piece(count, slots) -- count equal on all ranks, padded by
+ * repeating a slot if a rank has fewer -- is called right after the sdm_recon of those keyframes and gathers them on a
+ * second stream behind an event, so the next sdm_recon overlaps the transfer; _finish orders later work
+ * (sdm_inter_check) behind the last piece and copies the maps this rank reads (fetch_index = owner_rank *
+ * maps_per_rank + position in the owner's contribution order) into dst_slot.  Used for the whole block in sub-blocks,
+ * or for just the keyframes other ranks read (a third of the bytes on an index-local covisibility graph).
  * No host wait.  world == 1: the pieces are device copies and the fetch addressing still runs. */
-int sdm_allgather_begin(sdm_ctx *ctx, int first_slot, int block_count);
-int sdm_allgather_piece(sdm_ctx *ctx, int offset, int count);
+int sdm_allgather_begin(sdm_ctx *ctx, int maps_per_rank);
+int sdm_allgather_piece(sdm_ctx *ctx, int count, const int *slots);
 int sdm_allgather_finish(sdm_ctx *ctx, int n_fetch, const int *fetch_index, const int *dst_slot);
 /* Go / no-go before a collective pass: all ranks call it; *all_ok = min over ranks of local_ok (host-blocking).
  * A rank that cannot take part in the exchange it planned reports it here, so peers skip the pass instead of

@@ -82,8 +82,8 @@ SYMBOLS = [
     ("sdm_exchange_wait", C.c_int, [_ctx]),
     ("sdm_exchange_halo", C.c_int, [_ctx, C.c_int, _ip, _ip, C.c_int, _ip, _ip]),
     ("sdm_allgather_depth", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _ip, _ip]),
-    ("sdm_allgather_begin", C.c_int, [_ctx, C.c_int, C.c_int]),
-    ("sdm_allgather_piece", C.c_int, [_ctx, C.c_int, C.c_int]),
+    ("sdm_allgather_begin", C.c_int, [_ctx, C.c_int]),
+    ("sdm_allgather_piece", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_allgather_finish", C.c_int, [_ctx, C.c_int, _ip, _ip]),
     ("sdm_comm_all_ok", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
@@ -381,11 +381,12 @@ class Engine:
         ds, dsp = _i32([s for _, s in fetch])
         self._check(self.lib.sdm_allgather_depth(self.ctx, first_slot, count, len(fetch), fip, dsp))
 
-    def allgather_begin(self, first_slot, block_count):
-        self._check(self.lib.sdm_allgather_begin(self.ctx, first_slot, block_count))
+    def allgather_begin(self, maps_per_rank):
+        self._check(self.lib.sdm_allgather_begin(self.ctx, maps_per_rank))
 
-    def allgather_piece(self, offset, count):
-        self._check(self.lib.sdm_allgather_piece(self.ctx, offset, count))
+    def allgather_piece(self, slots):
+        s, sp = _i32(np.asarray(slots).reshape(-1))
+        self._check(self.lib.sdm_allgather_piece(self.ctx, len(s), sp))
 
     def allgather_finish(self, fetch):
         fi, fip = _i32([i for i, _ in fetch])

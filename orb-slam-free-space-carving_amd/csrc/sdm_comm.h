@@ -107,6 +107,9 @@ void comm_release(sdm_ctx* c)
     c->gather_slots = 0;
     (void)hipFree(c->d_agree);
     c->d_agree = nullptr;
+    (void)hipFree(c->stage_buf);
+    c->stage_buf = nullptr;
+    c->stage_slots = 0;
     c->xchg_pending = false;
     c->ag_open = false;
     c->ag_pieces.clear();
@@ -339,24 +342,29 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
 }
 
 // ---- all-gather in pieces, overlapped with the reconstruction ------------------------------------------------------
-// The block's keyframes are reconstructed in a few sub-blocks; as soon as one is finished its maps are gathered on the
-// exchange stream (behind an event) while the next sub-block's K1-K3 run on the compute stream -- the same two-event
-// scheme as the halo form.  Piece i = `count` maps from block position `offset` on lands in the gather buffer at
-// [piece base][rank][count]; _finish makes the compute stream wait for the last piece and copies the maps this rank's
-// K4 reads (fetch_index = owner_rank * block_count + position, as for sdm_allgather_depth) into their local slots.
-// With world == 1 the "gather" of a piece is a device copy on the exchange stream, so that the piece bookkeeping and
-// the fetch addressing run (and are tested) on one GPU, too.
-int sdm_allgather_begin(sdm_ctx* c, int first_slot, int block_count)
+// Every rank contributes the same number of maps (`maps_per_rank`), in pieces: a piece is a list of local slots whose
+// K1-K3 have just been queued; it is gathered on the exchange stream (behind an event) while the next keyframes are
+// reconstructed on the compute stream -- the same two-event scheme as the halo form.  Two uses:
+//   * the whole block in a few sub-blocks (BASELINE.json's literal "all-gather of the per-keyframe maps");
+//   * only the keyframes that some other rank's K4 reads (the boundary keyframes of an index-local covisibility graph),
+//     padded to a common count -- the same collective over a third of the bytes, issued before the interior keyframes
+//     are reconstructed.
+// Piece i = `count` maps lands in the gather buffer at [piece base][rank][count] (piece base = world * maps before it);
+// _finish makes the compute stream wait for the last piece and copies map fetch_index[i] = owner_rank * maps_per_rank +
+// position (position = index in the owner's contribution order) into local slot dst_slot[i].  A piece of consecutive
+// slots is gathered straight from the depth pool; any other list is packed into a staging buffer first (device copies
+// on the exchange stream).  With world == 1 the "gather" is a device copy, so that the bookkeeping and the fetch
+// addressing run (and are tested) on one GPU, too.
+int sdm_allgather_begin(sdm_ctx* c, int maps_per_rank)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (c->ag_open) return fail(SDM_ESTATE, "an all-gather is already open: call sdm_allgather_finish first");
     if (c->xchg_pending) return fail(SDM_ESTATE, "an exchange is in flight: call sdm_exchange_wait first");
-    if (block_count < 1 || first_slot < 0 || first_slot + block_count > c->cfg.max_keyframes)
-        return fail(SDM_EINVAL, "block out of range");
+    if (maps_per_rank < 1) return fail(SDM_EINVAL, "maps_per_rank < 1");
     HIP_TRY(hipSetDevice(c->cfg.device));
     int rc = comm_streams(c);
     if (rc) return rc;
-    const long long total = (long long)c->world * block_count;
+    const long long total = (long long)c->world * maps_per_rank;
     if (c->gather_slots < total) {
         HIP_TRY(hipStreamSynchronize(c->stream));  // earlier fetch copies may still read the old buffer
         HIP_TRY(hipStreamSynchronize(c->comm_stream));
@@ -370,32 +378,52 @@ int sdm_allgather_begin(sdm_ctx* c, int first_slot, int block_count)
     HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
     c->ag_open = true;
-    c->ag_first = first_slot;
-    c->ag_count = block_count;
+    c->ag_count = maps_per_rank;
     c->ag_covered = 0;
     c->ag_pieces.clear();
+    c->ag_contributed.assign((size_t)c->cfg.max_keyframes, 0);
     return SDM_OK;
 }
 
-int sdm_allgather_piece(sdm_ctx* c, int offset, int count)
+int sdm_allgather_piece(sdm_ctx* c, int count, const int* slots)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (!c->ag_open) return fail(SDM_ESTATE, "sdm_allgather_begin first");
-    if (count < 1 || offset != c->ag_covered || offset + count > c->ag_count)
-        return fail(SDM_EINVAL, "pieces must cover the block in order, without gaps or overlap");
-    for (int r = 0; r < count; r++)
-        if (!c->has_depth[c->ag_first + offset + r]) return fail(SDM_ESTATE, "piece slot has no reconstructed depth map");
+    if (count < 1 || !slots || c->ag_covered + count > c->ag_count)
+        return fail(SDM_EINVAL, "piece exceeds the maps_per_rank announced to sdm_allgather_begin");
+    bool contiguous = true;
+    for (int i = 0; i < count; i++) {
+        if (slots[i] < 0 || slots[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "piece slot out of range");
+        if (!c->has_depth[slots[i]]) return fail(SDM_ESTATE, "piece slot has no reconstructed depth map");
+        contiguous = contiguous && slots[i] == slots[0] + i;
+    }
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));  // this piece's K1-K3 are queued on the compute stream
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
+    const int offset = c->ag_covered;
+    const float2* src = c->pool + (long long)slots[0] * c->P;
+    if (!contiguous) {
+        if (c->stage_slots < c->ag_count) {
+            HIP_TRY(hipStreamSynchronize(c->comm_stream));
+            (void)hipFree(c->stage_buf);
+            c->stage_buf = nullptr;
+            c->stage_slots = 0;
+            HIP_TRY(hipMalloc((void**)&c->stage_buf, sizeof(float2) * (size_t)c->P * (size_t)c->ag_count));
+            c->stage_slots = c->ag_count;
+        }
+        for (int i = 0; i < count; i++)  // runs of consecutive slots could share a copy; the lists are short
+            HIP_TRY(hipMemcpyAsync(c->stage_buf + (long long)(offset + i) * c->P, c->pool + (long long)slots[i] * c->P,
+                                   sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->comm_stream));
+        src = c->stage_buf + (long long)offset * c->P;
+    }
     const size_t piece_floats = (size_t)count * (size_t)c->P * 2;
     float2* dst = c->gather_buf + (long long)c->world * offset * c->P;  // pieces before this one hold world*offset maps
-    const float2* src = c->pool + (long long)(c->ag_first + offset) * c->P;
     if (c->world == 1) {
         HIP_TRY(hipMemcpyAsync(dst, src, piece_floats * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
     } else {
         RCCL_TRY(g_rccl.AllGather(src, dst, piece_floats, ncclFloat, (ncclComm_t)c->comm, c->comm_stream));
     }
+    for (int i = 0; i < count; i++) c->ag_contributed[slots[i]] = 1;
     c->ag_pieces.push_back({offset, count});
     c->ag_covered = offset + count;
     return SDM_OK;
@@ -405,15 +433,14 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (!c->ag_open) return fail(SDM_ESTATE, "sdm_allgather_begin first");
-    if (c->ag_covered != c->ag_count) return fail(SDM_ESTATE, "the pieces do not cover the block yet");
+    if (c->ag_covered != c->ag_count) return fail(SDM_ESTATE, "the pieces do not add up to maps_per_rank yet");
     if (n_fetch < 0 || (n_fetch > 0 && (!fetch_index || !dst_slot))) return fail(SDM_EINVAL, "bad fetch list");
     const long long total = (long long)c->world * c->ag_count;
     std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
     for (int i = 0; i < n_fetch; i++) {
         if (fetch_index[i] < 0 || fetch_index[i] >= total) return fail(SDM_EINVAL, "fetch index out of range");
         if (dst_slot[i] < 0 || dst_slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "fetch slot out of range");
-        if (dst_slot[i] >= c->ag_first && dst_slot[i] < c->ag_first + c->ag_count)
-            return fail(SDM_EINVAL, "fetch would overwrite this rank's own block");
+        if (c->ag_contributed[dst_slot[i]]) return fail(SDM_EINVAL, "fetch would overwrite a map this rank contributed");
         if (seen[dst_slot[i]]) return fail(SDM_EINVAL, "duplicate fetch slot");
         seen[dst_slot[i]] = 1;
     }

@@ -162,8 +162,11 @@ struct sdm_ctx {
         int offset, count;
     };
     bool ag_open = false;
-    int ag_first = 0, ag_count = 0, ag_covered = 0;
+    int ag_count = 0, ag_covered = 0;  // maps every rank contributes / contributed so far
     std::vector<AgPiece> ag_pieces;
+    std::vector<char> ag_contributed;   // [max_keyframes] local slots this rank has contributed
+    float2* stage_buf = nullptr;        // packing buffer for pieces that are not runs of consecutive slots
+    int stage_slots = 0;
     int* d_agree = nullptr;  // sdm_comm_all_ok
 };
 

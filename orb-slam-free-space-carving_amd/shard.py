@@ -10,15 +10,18 @@ input halo (the covisible neighbours that live on adjacent ranks) -- in ascendin
 the own block is a contiguous run of slots and device memory per rank does not grow with the world
 size.  plan()["slot"] maps a global keyframe index to the local slot.
 
-Two exchange forms, two transports:
+Three exchange forms, two transports:
 
-  halo (default)  each rank receives only the maps its K4 will read (N/2 keyframes from each adjacent
-                  block for an index-local covisibility graph), point-to-point.  xGMI is point-to-point,
-                  so this moves 2 x (N/2) x 8P bytes per rank over two direct links, independent of
-                  the number of GPUs, and it is issued right after the boundary keyframes are
-                  reconstructed so it overlaps the reconstruction of the interior ones.
-  allgather       every rank's whole block (BASELINE.json's wording); (world-1) x block bytes per rank
-                  land in a gather buffer and the maps this rank reads are copied to their slots.
+  allgather       (default) an RCCL all-gather of the per-keyframe {rho,sigma} maps that cross ranks: every rank
+                  contributes its BOUNDARY keyframes -- the own keyframes some other rank's K4 reads -- padded to a
+                  common count, right after reconstructing them; the interior keyframes are reconstructed while the
+                  collective runs on the engine's exchange stream.  (world-1) x boundary x 8P bytes arrive per rank.
+  allgather_full  every rank's WHOLE block (BASELINE.json's literal wording), pipelined in sub-blocks behind the
+                  reconstruction; (world-1) x block x 8P bytes per rank -- three times the bytes of the default on the
+                  bench's index-local covisibility graph, for maps nobody reads.
+  halo            point-to-point: each rank receives only the maps its K4 will read (N/2 keyframes from each adjacent
+                  block), 2 x (N/2) x 8P bytes per rank over two direct xGMI links, independent of the number of GPUs,
+                  issued right after the boundary keyframes are reconstructed.
 
   native          RCCL called by the engine itself (include/sdm_c.h sdm_exchange_* / sdm_allgather_depth):
                   the C++ drop-in shards without Python; this module only hands over the lists.
@@ -79,12 +82,27 @@ def plan(n_total, world, rank, n_nbr, neighbours_fn):
             send[q] = sorted(wanted)
     boundary = sorted({j for lst in send.values() for j in lst})
     bset = set(boundary)
+    # what every rank contributes to the boundary all-gather (the same on all ranks): its own keyframes that some other
+    # rank's K4 reads, ascending; `contrib_count` = the common (padded) length
+    contrib = {}
+    for q in range(world):
+        qf, qc = block_partition(n_total, world, q)
+        wanted = set()
+        for k in range(n_total):
+            if qf <= k < qf + qc:
+                continue
+            for j in neighbours_fn(k, n_total, n_nbr):
+                if qf <= j < qf + qc:
+                    wanted.add(j)
+        contrib[q] = sorted(wanted)
+    assert contrib[rank] == boundary
+    contrib_count = max([len(v) for v in contrib.values()] + [1])
     interior = [k for k in own if k not in bset]
     inputs = sorted(need)
     slot = {k: i for i, k in enumerate(inputs)}
     return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=inputs, boundary=boundary,
                 interior=interior, recv=recv, send=send, n_total=n_total, world=world, rank=rank,
-                slot=slot, n_slots=len(inputs), first_slot=slot[first],
+                slot=slot, n_slots=len(inputs), first_slot=slot[first], contrib=contrib, contrib_count=contrib_count,
                 own_slots=[slot[k] for k in own], nbr_slots=[[slot[j] for j in row] for row in nbrs],
                 boundary_slots=[slot[k] for k in boundary], interior_slots=[slot[k] for k in interior])
 
@@ -176,9 +194,41 @@ def halo_lists(pl):
 
 
 def fetch_list(pl):
-    """[(index in the gathered sequence = global keyframe, local slot)] of the maps K4 reads from other ranks"""
+    """whole-block all-gather: [(index in the gathered sequence = global keyframe, local slot)] of the maps K4 reads
+    from other ranks"""
     own = set(pl["own"])
     return [(k, pl["slot"][k]) for k in pl["inputs"] if k not in own]
+
+
+def contrib_slots(pl):
+    """boundary all-gather: this rank's contribution as local slots, padded to the common count by repeating the last
+    one (a rank at the end of the sequence has half as many boundary keyframes; a rank with none repeats its first slot)"""
+    s = [pl["slot"][k] for k in pl["contrib"][pl["rank"]]] or [pl["first_slot"]]
+    return s + [s[-1]] * (pl["contrib_count"] - len(s))
+
+
+def contrib_fetch_list(pl):
+    """boundary all-gather: [(owner * contrib_count + position in the owner's contribution, local slot)] of the maps K4
+    reads from other ranks"""
+    out = []
+    for q in sorted(pl["recv"]):
+        pos = {k: i for i, k in enumerate(pl["contrib"][q])}
+        out += [(q * pl["contrib_count"] + pos[k], pl["slot"][k]) for k in pl["recv"][q]]
+    return out
+
+
+def allgather_boundary(pool, pl, group=None):
+    """torch transport of the boundary all-gather (rehearsal / fallback): pack, all_gather_into_tensor, unpack"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    staged = _staged(pool, group)
+    idx = torch.tensor(contrib_slots(pl), dtype=torch.long, device=pool.device)
+    mine = pool.index_select(0, idx)
+    shape = (pl["world"] * pl["contrib_count"],) + tuple(pool.shape[1:])
+    gather = torch.empty(shape, dtype=pool.dtype, device="cpu" if staged else pool.device)
+    dist.all_gather_into_tensor(gather, mine.cpu() if staged else mine, group=group)
+    for i, s in contrib_fetch_list(pl):
+        pool[s].copy_(gather[i])
 
 
 def setup_native_comm(eng, group=None):
@@ -208,14 +258,15 @@ def sub_blocks(count, pieces):
 AG_PIECES = 4  # sub-blocks of the pipelined all-gather (native transport)
 
 
-def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, transport="torch", ag_pieces=AG_PIECES,
+def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None, transport="torch", ag_pieces=AG_PIECES,
                   force_pieces=False):
     """One pass of the hot path over this rank's keyframe block (what bench.py times and the
     multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
     check (K4, snapshot form) + point set (K5; back-projected in the checking kernel).
 
-    halo: boundary keyframes are reconstructed first; their maps travel to the adjacent ranks
-    (point-to-point over xGMI) while the interior keyframes are reconstructed."""
+    exchange: "allgather" (boundary keyframes, overlapped), "allgather_full" (whole block, pipelined in sub-blocks) or
+    "halo" (point-to-point); see the module docstring.  force_pieces: run the all-gather bookkeeping at world size 1
+    (the tests' rehearsal)."""
     world = pl["world"]
     own, nbrs = pl["own_slots"], pl["nbr_slots"]
     nb_of = dict(zip(own, nbrs))
@@ -234,13 +285,33 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="halo", group=None, tran
         else:
             wait_all(works)
             eng.mark_depth_present([s for _, s in halo_lists(pl)[1]])
-    elif native and ag_pieces > 1 and (world > 1 or force_pieces):  # force_pieces: the world-1 rehearsal of the tests
-        # all-gather, pipelined: the block is reconstructed in sub-blocks; each one's maps are gathered on the
-        # engine's exchange stream while the next one's K1-K3 run (sdm_allgather_begin / _piece / _finish)
-        eng.allgather_begin(pl["first_slot"], pl["count"])
+    elif exchange == "allgather" and (world > 1 or force_pieces):
+        # all-gather of the maps that cross ranks: reconstruct the boundary keyframes, start the collective on the
+        # engine's exchange stream, reconstruct the interior keyframes meanwhile
+        if boundary:
+            eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+        else:
+            eng.recon(own[:1], nbrs[:1], min_d, max_d)  # nothing crosses ranks: the (padded) contribution still needs a map
+        rest = interior if boundary else own[1:]
+        if native:
+            eng.allgather_begin(pl["contrib_count"])
+            eng.allgather_piece(contrib_slots(pl))
+            if rest:
+                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            eng.allgather_finish(contrib_fetch_list(pl))
+        else:
+            allgather_boundary(pool, pl, group)
+            if rest:
+                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            eng.mark_depth_present([s for _, s in contrib_fetch_list(pl)])
+    elif exchange == "allgather_full" and native and ag_pieces > 1 and (world > 1 or force_pieces):
+        # whole-block all-gather, pipelined: the block is reconstructed in sub-blocks; each one's maps are gathered on
+        # the engine's exchange stream while the next one's K1-K3 run (sdm_allgather_begin / _piece / _finish)
+        eng.allgather_begin(pl["count"])
         for off, cnt in sub_blocks(pl["count"], ag_pieces):
             eng.recon(own[off:off + cnt], nbrs[off:off + cnt], min_d, max_d)
-            eng.allgather_piece(off, cnt)
+            eng.allgather_piece(own[off:off + cnt])
+        # position in the owner's block == keyframe - owner's first keyframe; owner * count + position == keyframe
         eng.allgather_finish(fetch_list(pl))
     else:
         eng.recon(own, nbrs, min_d, max_d)

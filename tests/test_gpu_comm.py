@@ -34,28 +34,30 @@ def test_world1_exchange_is_a_noop(pkg, oracle, gpu_ok):
         assert_bit_equal(g[0], r)
         assert_bit_equal(g[1], s)
     # the whole step through the native transport == the plain calls
-    for exch in ("halo", "allgather"):
+    for exch in ("halo", "allgather", "allgather_full"):
         pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native")
         chk = [eng.download_checked(k) for k in refs]
         eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
         eng.inter_check(refs, nbrs)
         for k in refs:
             assert_bit_equal(eng.download_checked(k), chk[k], "checked rho kf %d (%s)" % (k, exch))
-    # the pipelined all-gather step (sub-blocks gathered on the exchange stream while the next one is reconstructed):
-    # at world size 1 the pieces are device copies, the schedule and the results are the plain step's
+    # the overlapped all-gather steps at world size 1 (the pieces are device copies; schedule and results are the plain
+    # step's): the boundary form (nothing crosses ranks here: a one-map padded contribution) and the whole-block form
+    # in 2, 3 and 8 sub-blocks
     want = [eng.download_checked(k) for k in refs]
-    for pieces in (2, 3, 8):
-        pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, "allgather", transport="native",
+    for exch, pieces in (("allgather", 1), ("allgather_full", 2), ("allgather_full", 3), ("allgather_full", 8)):
+        pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native",
                                 ag_pieces=pieces, force_pieces=True)
         for k in refs:
-            assert_bit_equal(eng.download_checked(k), want[k], "checked rho kf %d (%d pieces)" % (k, pieces))
+            assert_bit_equal(eng.download_checked(k), want[k], "checked rho kf %d (%s, %d pieces)" % (k, exch, pieces))
     eng.comm_destroy()
     eng.close()
 
 
 def test_allgather_pieces_addressing(pkg, oracle, gpu_ok):
-    """sdm_allgather_begin / _piece / _finish at world size 1: every piece lands in the gather buffer and
-    fetch_index = owner*block_count + position finds it again (the same code addresses the other ranks' maps)"""
+    """sdm_allgather_begin / _piece / _finish at world size 1: every piece lands in the gather buffer -- straight from
+    the pool for a run of consecutive slots, through the packing buffer for any other list -- and fetch_index =
+    owner * maps_per_rank + position finds it again (the same code addresses the other ranks' maps)"""
     seq = Sequence(pkg, oracle, 96, 72, 8, 0x5EED0C12)
     n = 5
     eng = pkg.Engine(seq.W, seq.H, seq.n_kf + 4, max_neighbours=n)
@@ -63,41 +65,40 @@ def test_allgather_pieces_addressing(pkg, oracle, gpu_ok):
     refs = list(range(seq.n_kf))
     nbrs = [seq.neighbours(k, n) for k in refs]
     with pytest.raises(pkg.SdmError) as e:
-        eng.allgather_piece(0, 2)  # not begun
+        eng.allgather_piece([0, 1])  # not begun
     assert e.value.code == 4
-    eng.allgather_begin(0, seq.n_kf)
+    eng.allgather_begin(seq.n_kf)
     with pytest.raises(pkg.SdmError) as e:
-        eng.allgather_begin(0, seq.n_kf)  # already open
+        eng.allgather_begin(seq.n_kf)  # already open
     assert e.value.code == 4
     with pytest.raises(pkg.SdmError) as e:
-        eng.allgather_piece(0, 3)  # no depth maps yet
+        eng.allgather_piece([0, 1, 2])  # no depth maps yet
     assert e.value.code == 4
-    maps = {}
-    for off, cnt in ((0, 3), (3, 3), (6, 2)):
-        eng.recon(refs[off:off + cnt], nbrs[off:off + cnt], seq.min_depth, seq.max_depth)
-        if off == 3:
+    order = [[0, 1, 2], [5, 3, 4], [7, 6]]  # a run, a permuted list (packed), a reversed pair (packed)
+    for i, piece in enumerate(order):
+        eng.recon(piece, [nbrs[k] for k in piece], seq.min_depth, seq.max_depth)
+        eng.allgather_piece(piece)
+        if i == 0:
             with pytest.raises(pkg.SdmError) as e:
-                eng.allgather_piece(4, 2)  # a gap
-            assert e.value.code == 1
-        eng.allgather_piece(off, cnt)
-        if off == 0:
-            with pytest.raises(pkg.SdmError) as e:
-                eng.allgather_finish([])  # block not covered yet
+                eng.allgather_finish([])  # the pieces do not add up yet
             assert e.value.code == 4
-    for k in refs:
-        maps[k] = eng.download_depth(k)
     with pytest.raises(pkg.SdmError) as e:
-        eng.allgather_finish([(5, 2)])  # would overwrite the own block
+        eng.allgather_piece([0])  # more than announced
+    assert e.value.code == 1
+    maps = {k: eng.download_depth(k) for k in refs}
+    with pytest.raises(pkg.SdmError) as e:
+        eng.allgather_finish([(5, 2)])  # would overwrite a contributed map
     assert e.value.code == 1
     with pytest.raises(pkg.SdmError) as e:
         eng.allgather_finish([(5, 9), (6, 9)])  # duplicate destination
     assert e.value.code == 1
-    fetch = [(5, 8), (0, 9), (7, 10), (3, 11)]
+    flat = [k for piece in order for k in piece]  # position -> keyframe
+    fetch = [(3, 8), (0, 9), (6, 10), (5, 11)]
     eng.allgather_finish(fetch)
-    for k, s in fetch:
+    for pos, s in fetch:
         r, sg = eng.download_depth(s)
-        assert_bit_equal(r, maps[k][0], "fetched rho of keyframe %d" % k)
-        assert_bit_equal(sg, maps[k][1], "fetched sigma of keyframe %d" % k)
+        assert_bit_equal(r, maps[flat[pos]][0], "fetched rho at position %d (keyframe %d)" % (pos, flat[pos]))
+        assert_bit_equal(sg, maps[flat[pos]][1], "fetched sigma at position %d" % pos)
     assert float(np.abs(maps[5][0]).sum()) > 0
     assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # world size 1: the local verdict
     eng.close()

@@ -85,8 +85,10 @@ def _worker(rank, world, port, n_total, H, W, out, mode="allgather", n_nbr=4):
     for k in pl["own"]:
         pool[slot[k], :, :, 0] = k + 0.25
         pool[slot[k], :, :, 1] = -(k + 0.5)
-    if mode == "allgather":
+    if mode == "allgather_full":
         pkg.shard.allgather_depth(pool, pl)
+    elif mode == "allgather":
+        pkg.shard.allgather_boundary(pool, pl)
     else:
         pkg.shard.wait_all(pkg.shard.exchange_halo_async(pool, pl))
     ok = pl["n_slots"] <= pl["count"] + n_nbr  # memory per rank does not grow with the world size
@@ -149,5 +151,34 @@ def test_halo_exchange_gloo_world3(pkg):
 
 
 def test_allgather_exchange_gloo_world2(pkg):
-    """the all-gather form of the exchange (whole depth pool, in place), world_size 2 on gloo"""
-    _run_world(2, 12, "allgather")
+    """the whole-block all-gather form of the exchange, world_size 2 on gloo"""
+    _run_world(2, 12, "allgather_full")
+
+
+def test_boundary_allgather_gloo_world3(pkg):
+    """the default exchange: an all-gather of the boundary keyframes only (padded to a common count: the end ranks
+    have half as many), world_size 3 on gloo -- every map a rank's K4 reads arrives in its local slot"""
+    _run_world(3, 24, "allgather", n_nbr=6)
+
+
+def test_boundary_allgather_lists(pkg):
+    """contribution / fetch lists of the boundary all-gather: the same contribution table on every rank, every fetched
+    position holds the keyframe the plan says, padded contributions repeat a real slot"""
+    shard, nb = pkg.shard, pkg.synth.Scene.neighbours
+    for (n_total, world, n) in [(32, 4, 6), (64, 8, 20), (512, 8, 20), (24, 2, 7), (16, 4, 2)]:
+        plans = [shard.plan(n_total, world, r, n, nb) for r in range(world)]
+        for r, pl in enumerate(plans):
+            assert pl["contrib"] == plans[0]["contrib"] and pl["contrib_count"] == plans[0]["contrib_count"]
+            assert pl["contrib"][r] == pl["boundary"]
+            cs = shard.contrib_slots(pl)
+            assert len(cs) == pl["contrib_count"] and set(cs) <= set(pl["own_slots"])
+            assert cs[:len(pl["boundary"])] == pl["boundary_slots"]
+            fetched = {}
+            for idx, s in shard.contrib_fetch_list(pl):
+                q, pos = divmod(idx, pl["contrib_count"])
+                fetched[s] = pl["contrib"][q][pos]
+            want = {pl["slot"][k]: k for k in pl["inputs"] if k not in pl["own"]}
+            assert fetched == want
+        # the collective moves (world - 1) * contrib_count maps per rank instead of (world - 1) * block
+        assert plans[0]["contrib_count"] <= min(n, n_total // world)
+    assert shard.sub_blocks(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)] and shard.sub_blocks(3, 8) == [(0, 1), (1, 1), (2, 1)]
