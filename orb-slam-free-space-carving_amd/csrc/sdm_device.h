@@ -371,7 +371,8 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 4  lerp weight from v_fract instead of floor + add + sub
 // bit 5  search range: min/max through v_med3 (no canonicalising v_max), clamps on the integers
 // bit 6  the in-plane-rotation wrap of PM.cc:425-426 with integer masks instead of compare + select
-// bit 7  (lost: +4 %) records through a buffer descriptor: hardware range check instead of the row clamp
+// bit 7  (lost: +4 %, tools/experiments/k1_buffer_loads.patch) records through a buffer descriptor: hardware range check
+//        instead of the row clamp
 // bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
 #ifndef SDM_K1_OPT
 #define SDM_K1_OPT 0x7f
@@ -501,16 +502,6 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
     const unsigned hi16 = (unsigned)max(hi, 0) << 4;
 #endif
     float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
-#if SDM_K1_OPT & 0x80
-    // records through a buffer descriptor over the neighbour's plane: the hardware range check returns zeros for any
-    // offset outside it, so the fetch row needs no clamp, and the row test of PM.cc:408 + N3 (1 <= yf < H-1) is an
-    // unsigned range test on the bit pattern of t = -yf (a positive yf orders like its bits; negative, NaN and huge
-    // values land outside) -- one comparison, no v_med3.  The row index of an invalid candidate is garbage; its
-    // record (whatever it is) is never used.
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(nbase), (short)0,
-                                                                          (int)((unsigned)W * (unsigned)H * 16u), 0x00020000);
-    const unsigned row_span = __float_as_uint((float)(H - 1)) - 0x3F800000u;  // bits(H-1) - bits(1.0f)
-#endif
     for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
         float yfs[SCAN_UNROLL];
         unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
@@ -518,19 +509,6 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
         const unsigned c0 = (unsigned)u0 << 4;
 #pragma unroll
         for (int k = 0; k < SCAN_UNROLL; k++) {
-#if SDM_K1_OPT & 0x80
-            const float t = ab * (u0f + (float)k) + cb;  // -yf, PM.cc:407,433
-            yfs[k] = -t;
-            rowok[k] = __builtin_amdgcn_uicmp(__float_as_uint(t) - 0xBF800000u, row_span, 36 /* unsigned < */);
-            int row;
-            asm("v_cvt_i32_f32_e64 %0, -%1" : "=v"(row) : "v"(t));  // saturating; the C cast is undefined out of range
-            const unsigned off = __umul24((unsigned)row, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
-#if SDM_ABLATE == 5
-            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
-#else
-            rs[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16 * k, 0));
-#endif
-#else
             float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
             float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
 #if SDM_K1_OPT & 0x01
@@ -547,7 +525,6 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
             rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
 #else
             rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
-#endif
 #endif
         }
         // keep each record one 16-byte gather issued here: without this hipcc splits the first record

@@ -463,7 +463,7 @@ __host__ __device__ inline size_t k1_lds_bytes(int n)
     // K1_OUTLIER_ROWS words per pixel
     const size_t cw = (nn + 3) / 4 > (size_t)K1_OUTLIER_ROWS ? (nn + 3) / 4 : (size_t)K1_OUTLIER_ROWS;
     return (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * nn + sizeof(unsigned) * (size_t)K1_PX * cw +
-           sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned long long) * K1_PX + 16;
+           sizeof(unsigned long long) * K1_BLOCK + sizeof(unsigned long long) * K1_PX + sizeof(unsigned) * K1_PX + 16;
 }
 
 // Pixels whose fusion neither bound settles are not finished by their workgroup: they are appended -- hypotheses and all --
@@ -562,7 +562,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     const int cnt_words = max((n + 3) >> 2, K1_OUTLIER_ROWS);
     unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cnt + (size_t)cnt_words * K1_PX);  // [4][64]
     unsigned long long* set0 = pmask + K1_BLOCK;  // [64] members (other than itself) of the FIRST hypothesis' compatible set
-    unsigned* xbase = reinterpret_cast<unsigned*>(set0 + K1_PX);  // [1] first open-list entry of this workgroup (or ~0u)
+    unsigned* cnt0 = reinterpret_cast<unsigned*>(set0 + K1_PX);  // [64] size of that set (without itself)
+    unsigned* xbase = cnt0 + K1_PX;  // [1] first open-list entry of this workgroup (or ~0u)
 
     // XCD-aware decode (blocks b and b+8 share an XCD): chunk c of EVERY reference keyframe runs on
     // XCD c % 8, reference index fastest, so the ~n keyframes that read the same region of a
@@ -621,7 +622,10 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         sgm[j * K1_PX + p] = h.y;
     }
     for (int q = w; q < cnt_words; q += K1_WAVES) cnt[q * K1_PX + p] = 0u;
-    if (w == 0) set0[p] = 0ull;
+    if (w == 0) {
+        set0[p] = 0ull;
+        cnt0[p] = 0u;
+    }
     pmask[tid] = mymask;
     __syncthreads();
 
@@ -649,29 +653,47 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     // pair loop itself.
     const int a0 = (int)__ffsll((long long)vm) - 1;  // first accepted hypothesis (-1 if none)
     bool self0 = false;
-    if (go) {
+    if (go) {  // case (1) only needs the SIZE of row a0's set: one counter add per wave
         const float2 ha = hyp[a0 * K1_PX + p];
         const float sa = sgm[a0 * K1_PX + p];
         self0 = sa * sa > 0.0f;  // the self pair: 0/s2 + 0/s2 is 0 (< 5.99) unless s2 = sigma*sigma is 0 or NaN (0/0)
-        unsigned long long m = 0;
+        unsigned c = 0;
         for (int bb = w; bb < n; bb += K1_WAVES) {
             const float2 hb = hyp[bb * K1_PX + p];  // "no hypothesis" rows hold rho = +Inf: never compatible
-            if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) m |= 1ull << bb;
+            if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) c++;
         }
-        if (m) atomicOr(&set0[p], m);
+        if (c) atomicAdd(&cnt0[p], c);
     }
     __syncthreads();
-    const unsigned long long S0 = go ? (set0[p] | (self0 ? (1ull << a0) : 0ull)) : 0ull;
-    const int s0 = __popcll(S0);
 #if SDM_ABLATE == 9  // diagnostic build: never take a shortcut (every fusing pixel runs the all-pairs count)
     bool settled = false;
     const bool few = false;
+    const unsigned long long S0 = 0ull;
+    const int s0 = 0;
 #else
-    bool settled = go && self0 && s0 == nh;  // case (1)
+    bool settled = go && self0 && (int)cnt0[p] + 1 == nh;  // case (1)
+    // case (2) needs the MEMBERS of S0: row a0 once more, for the workgroups that still have an open pixel (none on
+    // clean data).  Lanes are pixels in every wave, so the ballots below have the same value in all four waves.
+    const bool more = go && !settled && self0;
+    unsigned long long S0 = settled ? vm : 0ull;
+    if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+        if (more) {
+            const float2 ha = hyp[a0 * K1_PX + p];
+            const float sa = sgm[a0 * K1_PX + p];
+            unsigned long long m = 0;
+            for (int bb = w; bb < n; bb += K1_WAVES) {
+                const float2 hb = hyp[bb * K1_PX + p];
+                if (bb != a0 && chi_test_lazy(ha, hb, sa, &sgm[bb * K1_PX + p])) m |= 1ull << bb;
+            }
+            if (m) atomicOr(&set0[p], m);
+        }
+        __syncthreads();
+        if (more) S0 = set0[p] | (1ull << a0);
+    }
+    const int s0 = __popcll(S0);
     const unsigned long long O = vm & ~S0;
     // case (2) candidates: a0 compatible with itself, at most K1_OUTLIER_ROWS rows outside its set
-    const bool few = go && !settled && self0 && __popcll(O) <= K1_OUTLIER_ROWS;
-    // lanes are pixels in every wave, so the ballots below have the same value in all four waves: uniform branches
+    const bool few = more && __popcll(O) <= K1_OUTLIER_ROWS;
     if (__builtin_amdgcn_ballot_w64(few) != 0ull) {
         unsigned* orow = cnt;  // [K1_OUTLIER_ROWS][64]: set size of the i-th outlier row, + 0x10000 per member of S0 it is
                                // compatible with (the pair loop's counters are not in use yet; re-zeroed below)
