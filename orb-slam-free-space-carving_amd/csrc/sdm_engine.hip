@@ -64,11 +64,12 @@ struct sdm_ctx {
     int* d_act_count = nullptr;    // [max_keyframes]
     int* d_theta_bad = nullptr;    // [max_keyframes] GradTheta plane holds a value outside [0,360] (k_pack)
     // K1's open-pixel list (pixels whose fusion the bounds do not settle; finished by k_fuse_open)
-    unsigned* d_open_ctr = nullptr;  // two {count, first overflow} pairs, used alternately by successive launches
+    unsigned* d_open_ctr = nullptr;  // two sets of 4 counters (OpenList::count), used alternately by successive launches
     long long* d_open_pix = nullptr;
     unsigned long long* d_open_vm = nullptr;
     float2* d_open_hyp = nullptr;
     unsigned open_capacity = 0;
+    unsigned open_quota = 512;
     unsigned open_launch = 0;
     unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
@@ -594,14 +595,15 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         // count their open pixels in place (slower, same result)
         long long cap = std::min<long long>(1ll << 20, std::max<long long>(K1_PX, c->P * K / 4));
         if (const char* e = getenv("SDM_K4_PAD")) c->k4_lds_pad = (unsigned)atoi(e);
+        if (const char* e = getenv("SDM_OPEN_QUOTA")) c->open_quota = (unsigned)atoll(e);  // tests: 0 defers every open pixel
         if (const char* e = getenv("SDM_OPEN_CAPACITY"))  // tests: a tiny list forces the in-place fallback
             cap = std::max<long long>(K1_PX, std::min<long long>(cap, atoll(e)));
         c->open_capacity = (unsigned)(cap / K1_PX * K1_PX);
-        if ((rc = dev_alloc(&c->d_open_ctr, 4)) || (rc = dev_alloc(&c->d_open_pix, (size_t)c->open_capacity)) ||
+        if ((rc = dev_alloc(&c->d_open_ctr, 8)) || (rc = dev_alloc(&c->d_open_pix, (size_t)c->open_capacity)) ||
             (rc = dev_alloc(&c->d_open_vm, (size_t)c->open_capacity)) ||
             (rc = dev_alloc(&c->d_open_hyp, (size_t)c->open_capacity * cfg->max_neighbours)))
             return bail(rc);
-        const unsigned init[4] = {0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
+        const unsigned init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
         if (hipMemcpy(c->d_open_ctr, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(SDM_EHIP, "open-list counter initialisation failed"));
     }
@@ -902,9 +904,10 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     const size_t lds = k1_lds_bytes(n);
     const int blocks_per_ref = 8 * ((max_chunks + 7) / 8);
     OpenList ol;
-    ol.count = c->d_open_ctr + 2 * (c->open_launch & 1u);
-    ol.next = c->d_open_ctr + 2 * ((c->open_launch + 1u) & 1u);
+    ol.count = c->d_open_ctr + 4 * (c->open_launch & 1u);
+    ol.next = c->d_open_ctr + 4 * ((c->open_launch + 1u) & 1u);
     ol.capacity = c->open_capacity;
+    ol.quota = c->open_quota;
     ol.pix = c->d_open_pix;
     ol.vm = c->d_open_vm;
     ol.hyp = c->d_open_hyp;
@@ -912,7 +915,7 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     // the pixels the fusion bounds left open, 64 per workgroup; the list length stays on the device (a fixed grid walks
     // whatever is there, nothing when the list is empty)
     const size_t lds_open = (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * n + sizeof(unsigned) * (size_t)K1_PX * ((n + 3) / 4);
-    const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, 1024u);
+    const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, 512u);
     // (the slices of one call append to the same open list; k_fuse_open runs once behind the last one)
     for_ref_slices(n_ref, blocks_per_ref, K1_BLOCK, [&](int first, int count) {
         if (c->stats_on)
@@ -926,10 +929,10 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     });
     if (c->stats_on)
         hipLaunchKernelGGL(k_fuse_open<true>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
-                           c->d_stats);
+                           c->P * c->cfg.max_keyframes, c->d_stats);
     else
         hipLaunchKernelGGL(k_fuse_open<false>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
-                           c->d_stats);
+                           c->P * c->cfg.max_keyframes, c->d_stats);
     HIP_TRY(hipGetLastError());
     return SDM_OK;
 }

@@ -470,11 +470,16 @@ __host__ __device__ inline size_t k1_lds_bytes(int n)
 // to a per-launch list, and k_fuse_open runs the all-pairs count for 64 OPEN pixels per workgroup.  A clean workgroup
 // never pays the pair loop because one of its 64 pixels is open.
 struct OpenList {
-    unsigned* count;          // [0] entries reserved by this launch, [1] the first reservation that did not fit (else ~0u):
-                              // reservations are handed out in order, so the entries below min([0], [1]) are exactly the
-                              // ones that were written; a workgroup whose reservation did not fit finished its pixels itself
-    unsigned* next;           // the counter pair of the NEXT launch, reset by k_fuse_open (no memset between launches)
+    unsigned* count;          // this launch's counters: [0] open pixels seen so far (decides the quota below), [1] the first
+                              // list reservation that did not fit (else ~0u), [2] list entries reserved.  Reservations are
+                              // handed out in order, so the entries below min([2], [1]) are exactly the ones that were
+                              // written; a workgroup whose reservation did not fit finished its pixels itself
+    unsigned* next;           // the counters of the NEXT launch, reset by k_fuse_open (no memset between launches)
     unsigned capacity;        // entries the arrays hold (a multiple of 64)
+    unsigned quota;           // workgroups that find fewer than `quota` open pixels counted before theirs do not defer:
+                              // they count in place.  A launch with only a handful of open pixels (clean data) then leaves the list
+                              // empty and k_fuse_open returns at once -- a non-empty list costs its launch ~15 us of
+                              // latency (one workgroup's serial pair loop), however short it is.
     long long* pix;           // [capacity] element index into the depth pool
     unsigned long long* vm;   // [capacity] accepted-hypothesis mask
     float2* hyp;              // [capacity/64][n][64] {rho, sigma}
@@ -733,10 +738,15 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     if (open_mask != 0ull) {
         if (tid == 0) {
             const unsigned cntw = (unsigned)__popcll(open_mask);
-            const unsigned base = atomicAdd(&open_list.count[0], cntw);
-            const bool fits = base + cntw <= open_list.capacity;
-            if (!fits) atomicMin(&open_list.count[1], base);
-            xbase[0] = fits ? base : 0xFFFFFFFFu;
+            unsigned first = 0xFFFFFFFFu;  // count in place
+            if (atomicAdd(&open_list.count[0], cntw) >= open_list.quota) {
+                const unsigned base = atomicAdd(&open_list.count[2], cntw);  // entries base .. base+cntw-1 of the list
+                if (base <= open_list.capacity && cntw <= open_list.capacity - base)
+                    first = base;
+                else
+                    atomicMin(&open_list.count[1], base);
+            }
+            xbase[0] = first;
         }
         __syncthreads();  // also orders the counter re-zeroing above before the pair loop below
         const unsigned base = xbase[0];
@@ -797,18 +807,20 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
 // LDS layout and the same counting / fusion code as K1's in-place fallback, so the result is the same bit for bit.
 template <bool STATS>
 __global__ __launch_bounds__(K1_BLOCK) void k_fuse_open(OpenList open_list, int n, DevParams prm, float2* __restrict__ pool,
-                                                        unsigned long long* __restrict__ stats)
+                                                        long long pool_elems, unsigned long long* __restrict__ stats)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* hyp = reinterpret_cast<float2*>(smem_raw);               // [n][64] {rho, 1/sigma^2}
     float* sgm = reinterpret_cast<float*>(hyp + (size_t)n * K1_PX);  // [n][64] sigma
     unsigned* cnt = reinterpret_cast<unsigned*>(sgm + (size_t)n * K1_PX);
     const int cnt_words = (n + 3) >> 2;
-    const unsigned total = min(open_list.count[0], open_list.count[1]);
+    // entries 0 .. total-1 were written (see OpenList::count); never more than the arrays hold
+    const unsigned total = min(min(open_list.count[2], open_list.count[1]), open_list.capacity);
     const int tid = threadIdx.x, p = tid & (K1_PX - 1);
-    if (blockIdx.x == 0 && tid == 0) {  // the next launch's pair: nobody uses it before this kernel has finished
+    if (blockIdx.x == 0 && tid == 0) {  // the next launch's counters: nobody uses them before this kernel has finished
         open_list.next[0] = 0u;
         open_list.next[1] = 0xFFFFFFFFu;
+        open_list.next[2] = 0u;
     }
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long n_fused = 0;
@@ -829,7 +841,8 @@ __global__ __launch_bounds__(K1_BLOCK) void k_fuse_open(OpenList open_list, int 
         if (w == 0 && on) {
             float2 result = make_float2(0.f, 0.f);
             if (k1_fuse_counted(hyp, sgm, cnt, vm, n, p, prm.lambdaN, result)) n_fused++;
-            pool[open_list.pix[e]] = result;
+            const long long px = open_list.pix[e];
+            if (px >= 0 && px < pool_elems) pool[px] = result;  // (an entry is always in range; a store that is not never leaves)
         }
         __syncthreads();  // the LDS block is reused by the next list block
     }

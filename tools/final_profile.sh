@@ -1,7 +1,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/final
-timeout -k 10 300 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err || echo "bench failed"
+timeout -k 10 500 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err || echo "bench failed"
 tail -c 400 gpurun_out/final/bench.json
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -- python3 bench.py --steps 10 --warmup 2 --cpu-kfs 0 --no-extra > gpurun_out/final/kt.log 2>&1 || echo "kernel trace failed"
 f=$(find gpurun_out/final/kt -name "*kernel_stats.csv" | head -1)
@@ -11,4 +11,7 @@ rm -rf gpurun_out/final/kt
 timeout -k 10 200 python bench.py --kfs 256 --cpu-kfs 4 > gpurun_out/final/bench_480p_256kf_n20.json 2>> gpurun_out/final/bench.err || echo "256kf failed"
 timeout -k 10 200 python bench.py --res 720p --kfs 256 --nbrs 7 --cpu-kfs 3 > gpurun_out/final/bench_720p_256kf_n7.json 2>> gpurun_out/final/bench.err || echo "720p failed"
 timeout -k 10 200 python bench.py --res 1080p --kfs 64 --nbrs 7 --cpu-kfs 2 > gpurun_out/final/bench_1080p_64kf_n7.json 2>> gpurun_out/final/bench.err || echo "1080p failed"
+timeout -k 10 100 python tools/latency.py 7 > gpurun_out/final/latency.txt 2>&1 || echo "latency failed"
+timeout -k 10 100 python tools/latency.py 20 >> gpurun_out/final/latency.txt 2>&1 || echo "latency failed"
+cat gpurun_out/final/latency.txt
 echo done benches

@@ -23,6 +23,7 @@ WRITE_SIZE
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_READ_sum
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAVES GRBM_GUI_ACTIVE
+SQ_ACTIVE_INST_VALU2 SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
 GROUPS
 PMC_BENCH_ARGS="$*" python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 rm -rf "$OUT"/p[0-9]*
