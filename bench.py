@@ -3,22 +3,27 @@
 
 One "step" = one pass of the whole path over this rank's block of keyframes:
   SemiDenseRecon (epipolar search + fusion + intra-keyframe check/grow, PM.cc:137-256)
-  -> [N>1: exchange of the per-keyframe {rho,sigma} maps over RCCL: halo point-to-point or all-gather]
+  -> [N>1: exchange of the per-keyframe {rho,sigma} maps over RCCL: all-gather of the maps that cross ranks (default),
+      all-gather of the whole block, or point-to-point halo -- all three are timed, `value` is the --exchange one]
   -> InterKeyFrameDepthChecking (PM.cc:628-799) -> UpdateSemiDensePointSet (PM.cc:337-367)
 with every input already resident in HBM (search records packed before the timed region).
 
-`value` is measured on BASELINE.json configs[1] -- 640x480, 64 keyframes x 20 covisible neighbours,
-synthetic gradient images.  At N=1 the same JSON line carries `extra_configs`: the north_star's target
-case (640x480 x 256 keyframes, N=20) and configs[2] (1280x720 x 256 keyframes, N=7), each with its own
-ms_per_step, K1 roofline and mean scan length.  Weak scaling: every rank owns --kfs keyframes of one
-N*kfs sequence (--independent: one separate sequence per GPU, configs[4]).
+`value` is measured on BASELINE.json configs[1] -- 640x480, 64 keyframes x 20 covisible neighbours, synthetic gradient
+images -- in steady state (after a 0.3 s pre-warm phase; the same W + K steps straight after set-up are reported as
+value_cold / ms_per_step_cold / roofline.frac_cold).  At N=1 the same JSON line carries `extra_configs`: the
+north_star's target case (640x480 x 256 keyframes, N=20), configs[2] (1280x720 x 256 keyframes, N=7), configs[1] with two
+outlier neighbours per keyframe (K1 only), configs[1] on i.i.d.-noise images (SURVEY.md §8d adversarial set) and
+configs[1] with a long baseline (10 px/keyframe), each with its own ms_per_step, K1 roofline and mean scan length.
+Weak scaling: every rank owns --kfs keyframes of one N*kfs sequence (--independent: one separate sequence per GPU,
+configs[4]).
 
-`python bench.py --gpus N` with N>1 starts its own `torch.distributed.run` child (before anything
-touches the GPU) when it was not launched by one; the line printed is the child's.
+`python bench.py --gpus N` with N>1 starts its own `torch.distributed.run` child (before anything touches the GPU) when it
+was not launched by one; the line printed is the child's.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_search_fuse, HIP events on the
-engine's stream, algorithmic bytes P*(17+9N) per keyframe) and `cpu_baseline` (the CPU oracle
-timed on this box's host cores on a bounded sample; a reported baseline, not the target).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_search_fuse + its follow-up k_fuse_open, HIP events on
+the engine's stream, algorithmic bytes P*(17+9N) per keyframe; `bound` = what the counters say limits it),
+`step_roofline` (all kernels' algorithmic bytes over the step time) and `cpu_baseline` (the CPU oracle timed on this
+box's host cores on a bounded sample; a reported baseline, not the target).
 """
 import argparse
 import hashlib
