@@ -1,3 +1,6 @@
+"""Debug aid: K1 / K2 / K3 / recon of keyframe 0 against the oracle at 1920x1080, N = 7, for a sequence of n_total keyframes
+reconstructed in ONE call (how the 2^31-work-item launch limit was found).
+usage: python tools/debug/stage_vs_oracle_1080p.py N_TOTAL EXT_POOL(0|1)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
