@@ -370,6 +370,9 @@ def main():
 
     def barrier():
         if world > 1:
+            # drain this rank's queues first: the engine's exchange runs on its own RCCL communicator, and collectives of
+            # two communicators must not be in flight together (ranks could start them in different orders)
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -386,17 +389,28 @@ def main():
         # self-check.  If any rank fails (library, communicator or transfer error) ALL ranks agree -- over the
         # torch.distributed group -- to fall back to the torch transport, and the JSON line says so.
         ok, why = 1, ""
+
+        def agreed(ok):
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
         try:
             pkg.shard.setup_native_comm(eng)
-            wl.step("halo", "native")
-            wl.step("allgather", "native")
-            wl.step("allgather_full", "native")
-            torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 -- reported, never swallowed
             ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        if agreed(ok):  # every rank holds a communicator: only now may anyone post a transfer
+            try:
+                wl.step("halo", "native")
+                wl.step("allgather", "native")
+                wl.step("allgather_full", "native")
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            ok = 1 if agreed(ok) else 0
+        else:
+            ok = 0
+        if ok == 1:
             rccl_world = eng.comm_info()[0]
         else:
             transport = "torch"

@@ -115,12 +115,49 @@ void comm_release(sdm_ctx* c)
     c->ag_pieces.clear();
 }
 
+// Up to COPY_BATCH whole {rho,sigma} maps moved by ONE launch (blockIdx.y = map): the exchange's packing and
+// fetch steps move ~N maps per pass, and N back-to-back hipMemcpyAsync calls cost more in launch gaps than in bytes.
+constexpr int COPY_BATCH = 32;
+struct CopyBatch {
+    const float4* src[COPY_BATCH];
+    float4* dst[COPY_BATCH];
+};
+__global__ __launch_bounds__(BLOCK) void k_copy_maps(CopyBatch b, long long n16 /* 16-byte units per map */)
+{
+    const float4* __restrict__ s = b.src[blockIdx.y];
+    float4* __restrict__ d = b.dst[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (long long)gridDim.x * BLOCK) d[i] = s[i];
+}
+// maps are P float2: 16-byte units when P is even (every supported W is), plain copies otherwise
+int copy_maps(sdm_ctx* c, int n, const float2* const* src, float2* const* dst, hipStream_t stream)
+{
+    if ((c->P & 1) != 0) {
+        for (int i = 0; i < n; i++)
+            HIP_TRY(hipMemcpyAsync(dst[i], src[i], sizeof(float2) * c->P, hipMemcpyDeviceToDevice, stream));
+        return SDM_OK;
+    }
+    const long long n16 = (long long)c->P / 2;
+    const unsigned gx = (unsigned)std::min<long long>((n16 + BLOCK - 1) / BLOCK, 256);
+    for (int first = 0; first < n; first += COPY_BATCH) {
+        const int m = std::min(COPY_BATCH, n - first);
+        CopyBatch b;
+        for (int i = 0; i < COPY_BATCH; i++) {
+            b.src[i] = reinterpret_cast<const float4*>(src[first + (i < m ? i : 0)]);
+            b.dst[i] = reinterpret_cast<float4*>(dst[first + (i < m ? i : 0)]);
+        }
+        hipLaunchKernelGGL(k_copy_maps, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, n16);
+        HIP_TRY(hipGetLastError());
+    }
+    return SDM_OK;
+}
+
 int check_xchg_slots(sdm_ctx* c, int n, const int* peer, const int* slot, const char* what)
 {
     if (n < 0 || (n > 0 && (!peer || !slot))) return fail(SDM_EINVAL, std::string("bad ") + what + " list");
     for (int i = 0; i < n; i++) {
         if (slot[i] < 0 || slot[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, std::string(what) + " slot out of range");
-        if (peer[i] < 0 || peer[i] >= c->world || peer[i] == c->rank)
+        // (a one-rank communicator -- the hardware rehearsal of sdm_comm_init -- has only itself to talk to)
+        if (peer[i] < 0 || peer[i] >= c->world || (peer[i] == c->rank && c->world > 1))
             return fail(SDM_EINVAL, std::string(what) + " peer out of range (or self)");
     }
     return SDM_OK;
@@ -160,7 +197,12 @@ int sdm_comm_init(sdm_ctx* c, const unsigned char id[SDM_COMM_ID_BYTES], int wor
     if (!c) return fail(SDM_EINVAL, "null context");
     if (world < 1 || rank < 0 || rank >= world) return fail(SDM_EINVAL, "bad world/rank");
     if (c->comm || c->world != 1) return fail(SDM_ESTATE, "context already has a communicator");
-    if (world == 1) return SDM_OK;  // nothing to exchange: every sdm_exchange_* call is a no-op
+    // world 1: nothing to exchange, no communicator, every exchange call is a no-op or a device copy -- unless
+    // SDM_COMM_SINGLE_RANK_RCCL=1 asks for a real one-rank communicator: then every RCCL call of this file runs for real
+    // (an all-gather over one rank, sends to itself), which is how the transport is rehearsed on a one-GPU box
+    // (tests/test_gpu_comm.py)
+    const char* rehearse = getenv("SDM_COMM_SINGLE_RANK_RCCL");
+    if (world == 1 && !(rehearse && atoi(rehearse) == 1)) return SDM_OK;
     if (!id) return fail(SDM_EINVAL, "null id");
     int rc = load_rccl();
     if (rc) return rc;
@@ -186,7 +228,7 @@ int sdm_comm_attach(sdm_ctx* c, void* nccl_comm)
     int world = 0, rank = 0;
     RCCL_TRY(g_rccl.CommCount((ncclComm_t)nccl_comm, &world));
     RCCL_TRY(g_rccl.CommUserRank((ncclComm_t)nccl_comm, &rank));
-    if (world > 1 && (rc = comm_streams(c))) return rc;
+    if ((rc = comm_streams(c))) return rc;
     c->comm = nccl_comm;
     c->own_comm = false;
     c->world = world;
@@ -218,7 +260,7 @@ int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const 
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     if (c->xchg_pending) return fail(SDM_ESTATE, "an exchange is already in flight: call sdm_exchange_wait first");
-    if (c->world == 1) {
+    if (!c->comm) {
         if (n_send || n_recv) return fail(SDM_EINVAL, "world size 1 has no peers");
         return SDM_OK;
     }
@@ -309,7 +351,7 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
         return fail(SDM_EINVAL, "in-place all-gather needs slot == global keyframe index");
     for (int r = 0; r < count; r++)
         if (!c->has_depth[first_slot + r]) return fail(SDM_ESTATE, "block slot has no reconstructed depth map");
-    if (c->world == 1) return SDM_OK;  // this rank's block is all there is
+    if (!c->comm) return SDM_OK;  // this rank's block is all there is
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t block_floats = (size_t)count * (size_t)c->P * 2;
     ncclComm_t comm = (ncclComm_t)c->comm;
@@ -332,9 +374,15 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
     }
     RCCL_TRY(g_rccl.AllGather(c->pool + (long long)first_slot * c->P, c->gather_buf, block_floats, ncclFloat, comm,
                               c->stream));
+    std::vector<const float2*> srcs((size_t)n_fetch);
+    std::vector<float2*> dsts((size_t)n_fetch);
     for (int i = 0; i < n_fetch; i++) {
-        HIP_TRY(hipMemcpyAsync(c->pool + (long long)dst_slot[i] * c->P, c->gather_buf + (long long)fetch_index[i] * c->P,
-                               sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
+        srcs[i] = c->gather_buf + (long long)fetch_index[i] * c->P;
+        dsts[i] = c->pool + (long long)dst_slot[i] * c->P;
+    }
+    int rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_fetch; i++) {
         c->has_depth[dst_slot[i]] = 1;
         c->recon_lambdaG[dst_slot[i]] = std::nanf("");
     }
@@ -411,14 +459,19 @@ int sdm_allgather_piece(sdm_ctx* c, int count, const int* slots)
             HIP_TRY(hipMalloc((void**)&c->stage_buf, sizeof(float2) * (size_t)c->P * (size_t)c->ag_count));
             c->stage_slots = c->ag_count;
         }
-        for (int i = 0; i < count; i++)  // runs of consecutive slots could share a copy; the lists are short
-            HIP_TRY(hipMemcpyAsync(c->stage_buf + (long long)(offset + i) * c->P, c->pool + (long long)slots[i] * c->P,
-                                   sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->comm_stream));
+        std::vector<const float2*> srcs((size_t)count);
+        std::vector<float2*> dsts((size_t)count);
+        for (int i = 0; i < count; i++) {
+            srcs[i] = c->pool + (long long)slots[i] * c->P;
+            dsts[i] = c->stage_buf + (long long)(offset + i) * c->P;
+        }
+        int rc = copy_maps(c, count, srcs.data(), dsts.data(), c->comm_stream);
+        if (rc) return rc;
         src = c->stage_buf + (long long)offset * c->P;
     }
     const size_t piece_floats = (size_t)count * (size_t)c->P * 2;
     float2* dst = c->gather_buf + (long long)c->world * offset * c->P;  // pieces before this one hold world*offset maps
-    if (c->world == 1) {
+    if (!c->comm) {
         HIP_TRY(hipMemcpyAsync(dst, src, piece_floats * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
     } else {
         RCCL_TRY(g_rccl.AllGather(src, dst, piece_floats, ncclFloat, (ncclComm_t)c->comm, c->comm_stream));
@@ -447,14 +500,20 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
+    std::vector<const float2*> srcs((size_t)n_fetch);
+    std::vector<float2*> dsts((size_t)n_fetch);
     for (int i = 0; i < n_fetch; i++) {
         const int owner = fetch_index[i] / c->ag_count, pos = fetch_index[i] - owner * c->ag_count;
         const float2* src = nullptr;
         for (const auto& pc : c->ag_pieces)
             if (pos >= pc.offset && pos < pc.offset + pc.count)
                 src = c->gather_buf + ((long long)c->world * pc.offset + (long long)owner * pc.count + (pos - pc.offset)) * c->P;
-        HIP_TRY(hipMemcpyAsync(c->pool + (long long)dst_slot[i] * c->P, src, sizeof(float2) * c->P, hipMemcpyDeviceToDevice,
-                               c->stream));
+        srcs[i] = src;
+        dsts[i] = c->pool + (long long)dst_slot[i] * c->P;
+    }
+    int rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_fetch; i++) {
         c->has_depth[dst_slot[i]] = 1;
         c->recon_lambdaG[dst_slot[i]] = std::nanf("");
     }
@@ -469,7 +528,7 @@ int sdm_comm_all_ok(sdm_ctx* c, int local_ok, int* all_ok)
 {
     if (!c || !all_ok) return fail(SDM_EINVAL, "null argument");
     *all_ok = local_ok ? 1 : 0;
-    if (c->world == 1) return SDM_OK;
+    if (!c->comm) return SDM_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (!c->d_agree) HIP_TRY(hipMalloc((void**)&c->d_agree, sizeof(int)));
     const int v = local_ok ? 1 : 0;

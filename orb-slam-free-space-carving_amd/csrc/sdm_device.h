@@ -374,8 +374,9 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 7  (lost: +4 %, tools/experiments/k1_buffer_loads.patch) records through a buffer descriptor: hardware range check
 //        instead of the row clamp
 // bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
+// bit 9  GetFusion's 1/sigma^2 (double) from a float seed and three FMA steps instead of the IEEE double division
 #ifndef SDM_K1_OPT
-#define SDM_K1_OPT 0x7f
+#define SDM_K1_OPT 0x27f
 #endif
 
 // what one search reads of its PairConst, as float indices into the block `cv` points at: the PairConst itself
@@ -715,10 +716,32 @@ __device__ __forceinline__ double div_by_with_rcp(double a, double b, double r)
 __device__ __forceinline__ void fusion_terms(float rho, float sg, double& t_rho, double& t_one)
 {
     double s2 = (double)sg * (double)sg;
-    t_one = 1.0 / s2;
     const float ar = fabsf(rho);
+#if SDM_K1_OPT & 512
+    // 1.0 / s2 without the IEEE double division: float seed (<= 2^-21), two Newton steps (2^-42, then faithful),
+    // and one residual step that rounds correctly -- s2 = sigma^2 has at most 48 significant bits, so its
+    // significand is never all ones (the one case that step misses).  sdm_selftest(4) compares both terms with
+    // the plain divisions.  Outside 2^-100 < s2 < 2^100 (float square in range) the divisions themselves.
+    const unsigned hi = (unsigned)__double2hiint(s2);
+    const bool safe = ((hi - 0x39B00000u) < (0x46400000u - 0x39B00000u)) & (ar > 1.0e-30f) & (ar < 1.0e30f);
+    if (safe) {
+        double y = (double)__builtin_amdgcn_rcpf(sg * sg);
+        double e = __builtin_fma(-s2, y, 1.0);
+        y = __builtin_fma(e, y, y);
+        e = __builtin_fma(-s2, y, 1.0);
+        y = __builtin_fma(e, y, y);
+        e = __builtin_fma(-s2, y, 1.0);
+        t_one = __builtin_fma(e, y, y);
+        t_rho = div_by_with_rcp((double)rho, s2, t_one);
+    } else {
+        t_one = 1.0 / s2;
+        t_rho = (double)rho / s2;
+    }
+#else
+    t_one = 1.0 / s2;
     const bool safe = (s2 > 1.0e-60) & (s2 < 1.0e60) & (ar > 1.0e-30f) & (ar < 1.0e30f);
     t_rho = safe ? div_by_with_rcp((double)rho, s2, t_one) : (double)rho / s2;
+#endif
 }
 __device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, float& rsj)
 {

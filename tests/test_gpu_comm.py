@@ -1,8 +1,9 @@
 """GPU: the native exchange entry points of the C ABI (include/sdm_c.h sdm_comm_* / sdm_exchange_* /
 sdm_allgather_depth) at world size 1, where they must be exact no-ops, plus their argument checking.  The RCCL
-transport between GPUs cannot run on a one-GPU box (RCCL refuses two ranks on one device): UNMEASURED ON HARDWARE
-until the driver's multi-GPU run; the multi-rank control flow is covered with the torch/gloo transport in
-test_gpu_shard.py and the plan/list logic on CPU in test_shard_synth.py."""
+transport BETWEEN GPUs cannot run on a one-GPU box (RCCL refuses two ranks on one device): unmeasured on hardware
+until the driver's multi-GPU run.  What can run here does: test_rccl_single_rank_rehearsal drives every RCCL call
+of sdm_comm.h through a real one-rank communicator (SDM_COMM_SINGLE_RANK_RCCL=1); the multi-rank control flow is
+covered with the torch/gloo transport in test_gpu_shard.py and the plan/list logic on CPU in test_shard_synth.py."""
 import numpy as np
 import pytest
 
@@ -101,6 +102,76 @@ def test_allgather_pieces_addressing(pkg, oracle, gpu_ok):
         assert_bit_equal(sg, maps[flat[pos]][1], "fetched sigma at position %d" % pos)
     assert float(np.abs(maps[5][0]).sum()) > 0
     assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # world size 1: the local verdict
+    eng.close()
+
+
+def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
+    """Every RCCL call the exchange makes -- ncclGetUniqueId, ncclCommInitRank, ncclAllGather (from the pool, from the
+    packing buffer, in place, on the exchange stream and on the compute stream), grouped ncclSend/ncclRecv, ncclAllReduce,
+    ncclCommDestroy -- through a real communicator of ONE rank: librccl is loaded, the kernels run on this GPU, the
+    stream/event ordering is the multi-rank one, and every map that went through RCCL is bit-identical to its source."""
+    monkeypatch.setenv("SDM_COMM_SINGLE_RANK_RCCL", "1")
+    seq = Sequence(pkg, oracle, 96, 72, 8, 0x5EED0C13)
+    n = 5
+    eng = pkg.Engine(seq.W, seq.H, seq.n_kf + 6, max_neighbours=n)
+    seq.upload(eng, device_prepass=True)
+    eng.comm_init(eng.comm_unique_id(), 1, 0)
+    assert eng.comm_info() == (1, 0)
+    assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # ncclAllReduce(min)
+    refs = list(range(seq.n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    # pieces gathered while the next keyframes are reconstructed
+    eng.allgather_begin(seq.n_kf)
+    order = [[0, 1, 2], [5, 3, 4], [7, 6]]
+    for piece in order:
+        eng.recon(piece, [nbrs[k] for k in piece], seq.min_depth, seq.max_depth)
+        eng.allgather_piece(piece)
+    flat = [k for piece in order for k in piece]
+    fetch = [(3, 8), (0, 9), (6, 10), (5, 11)]
+    eng.allgather_finish(fetch)
+    maps = {k: eng.download_depth(k) for k in refs}
+    assert float(np.abs(maps[5][0]).sum()) > 0
+    for pos, s in fetch:
+        r, sg = eng.download_depth(s)
+        assert_bit_equal(r, maps[flat[pos]][0], "RCCL-gathered rho at position %d" % pos)
+        assert_bit_equal(sg, maps[flat[pos]][1], "RCCL-gathered sigma at position %d" % pos)
+    # the one-call forms: into the gather buffer + fetch, and in place
+    eng.allgather_depth(0, seq.n_kf, fetch=[(2, 12), (7, 13)])
+    for pos, s in ((2, 12), (7, 13)):
+        r, sg = eng.download_depth(s)
+        assert_bit_equal(r, maps[pos][0])
+        assert_bit_equal(sg, maps[pos][1])
+    eng2 = pkg.Engine(seq.W, seq.H, seq.n_kf, max_neighbours=n)
+    seq.upload(eng2, device_prepass=True)
+    eng2.comm_init(eng2.comm_unique_id(), 1, 0)
+    eng2.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    eng2.allgather_depth(0, seq.n_kf, fetch=None)
+    for k in refs:
+        r, sg = eng2.download_depth(k)
+        assert_bit_equal(r, maps[k][0], "in-place all-gather kf %d" % k)
+        assert_bit_equal(sg, maps[k][1])
+    eng2.comm_destroy()
+    eng2.close()
+    # grouped send / recv on the exchange stream (to itself: the only peer there is), overlapped with more compute
+    eng.exchange_halo_begin([(0, 1), (0, 6)], [(0, 8), (0, 9)])
+    eng.recon([2, 3], [nbrs[2], nbrs[3]], seq.min_depth, seq.max_depth)
+    eng.exchange_wait()
+    for src, dst in ((1, 8), (6, 9)):
+        r, sg = eng.download_depth(dst)
+        assert_bit_equal(r, maps[src][0], "self send/recv slot %d -> %d" % (src, dst))
+        assert_bit_equal(sg, maps[src][1])
+    # the three step forms of shard.pipeline_step over this communicator == the plain calls
+    pl = pkg.shard.plan(seq.n_kf, 1, 0, n, seq.scene.neighbours)
+    eng.recon(pl["own_slots"], pl["nbr_slots"], seq.min_depth, seq.max_depth)
+    eng.inter_check(pl["own_slots"], pl["nbr_slots"])
+    want = [eng.download_checked(k) for k in refs]
+    assert float(np.abs(want[4]).sum()) > 0
+    for exch, pieces in (("halo", 1), ("allgather", 1), ("allgather_full", 3)):
+        pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native",
+                                ag_pieces=pieces, force_pieces=True)
+        for k in refs:
+            assert_bit_equal(eng.download_checked(k), want[k], "checked rho kf %d (%s over RCCL)" % (k, exch))
+    eng.comm_destroy()
     eng.close()
 
 
