@@ -199,6 +199,9 @@ int sdm_allgather_depth(sdm_ctx *ctx, int first_slot, int count, int n_fetch, co
  * (sdm_inter_check) behind the last piece and copies the maps this rank reads (fetch_index = owner_rank *
  * maps_per_rank + position in the owner's contribution order) into dst_slot.  Used for the whole block in sub-blocks,
  * or for just the keyframes other ranks read (a third of the bytes on an index-local covisibility graph).
+ * The fetch copies run on the second stream too: between _begin and _finish the caller must not queue work that
+ * reads or writes the depth maps of the dst_slot keyframes -- anything else (sdm_recon of the next keyframes,
+ * sdm_inter_check of keyframes whose neighbours are all local) overlaps the transfer AND the copies.
  * No host wait.  world == 1: the pieces are device copies and the fetch addressing still runs. */
 int sdm_allgather_begin(sdm_ctx *ctx, int maps_per_rank);
 int sdm_allgather_piece(sdm_ctx *ctx, int count, const int *slots);

@@ -498,8 +498,9 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
         seen[dst_slot[i]] = 1;
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
+    // the fetch copies run on the EXCHANGE stream behind the last piece; the compute stream only waits for them.  What
+    // the caller queued on the compute stream before this call (the interior keyframes' K1-K3 and K4) neither reads nor
+    // writes the destination slots' maps, so the copies overlap it.
     std::vector<const float2*> srcs((size_t)n_fetch);
     std::vector<float2*> dsts((size_t)n_fetch);
     for (int i = 0; i < n_fetch; i++) {
@@ -511,8 +512,10 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
         srcs[i] = src;
         dsts[i] = c->pool + (long long)dst_slot[i] * c->P;
     }
-    int rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->stream);
+    int rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->comm_stream);
     if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
     for (int i = 0; i < n_fetch; i++) {
         c->has_depth[dst_slot[i]] = 1;
         c->recon_lambdaG[dst_slot[i]] = std::nanf("");

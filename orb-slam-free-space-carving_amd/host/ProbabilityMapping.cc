@@ -689,11 +689,34 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         ok = false;                     // failure is fatal for the communicator anyway
     }
     ok = run_recon(false) && ok;  // ... the rest while those maps travel
+    // PM.cc:300-306 for every keyframe of the block that is ready, snapshot order (the pool keeps the maps as
+    // reconstructed: commit = 0).  Keyframes whose neighbours are all this rank's own are checked BEFORE the wait -- more
+    // work for the transfer to hide behind -- the others after it.
+    std::vector<int> check_slot(plan.check.size(), -1);
+    auto run_check = [&](bool remote) {
+        std::vector<int> r, ns;
+        for (size_t a = 0; a < plan.check.size(); a++) {
+            bool reads_remote = false;
+            for (int j : plan.check_nbrs[a]) reads_remote = reads_remote || j < first || j >= first + count;
+            if (reads_remote != remote) continue;
+            check_slot[a] = slot[plan.check[a]];
+            r.push_back(check_slot[a]);
+            for (int j : plan.check_nbrs[a]) ns.push_back(slot[j]);
+        }
+        if (r.empty()) return true;
+        if (sdm_inter_check_pointset(ctx_, (int)r.size(), r.data(), n, ns.data(), /*commit=*/0) != SDM_OK) {
+            report("SemiDenseReconBlock");
+            return false;
+        }
+        return true;
+    };
+    bool checked = ok && run_check(false);
     if (sdm_exchange_wait(ctx_) != SDM_OK) {
         report("SemiDenseReconBlock");
         ok = false;
     }
     if (!ok) return;
+    checked = checked && run_check(true);
     // the maps as SemiDenseRecon left them (PM.cc:244)
     for (size_t a = 0; a < refs.size(); a++) {
         sdm::KeyFrame* kf = all[refs[a]];
@@ -701,25 +724,14 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         depth_on_device_[kf] = 1;
         kf->semidense_flag_ = true;
     }
-    // PM.cc:300-306 for every keyframe of the block that is ready, snapshot order
-    if (!plan.check.empty()) {
-        std::vector<int> r, ns;
-        for (size_t a = 0; a < plan.check.size(); a++) {
-            r.push_back(slot[plan.check[a]]);
-            for (int j : plan.check_nbrs[a]) ns.push_back(slot[j]);
-        }
-        if (sdm_inter_check_pointset(ctx_, (int)r.size(), r.data(), n, ns.data(), /*commit=*/0) != SDM_OK) {
+    if (!checked) return;
+    for (size_t a = 0; a < plan.check.size(); a++) {
+        sdm::KeyFrame* kf = all[plan.check[a]];
+        if (sdm_download_checked(ctx_, check_slot[a], kf->depth_map_.ptr()) != SDM_OK ||
+            sdm_download_pointset(ctx_, check_slot[a], kf->SemiDensePointSets_.ptr()) != SDM_OK)
             report("SemiDenseReconBlock");
-            return;
-        }
-        for (size_t a = 0; a < plan.check.size(); a++) {
-            sdm::KeyFrame* kf = all[plan.check[a]];
-            if (sdm_download_checked(ctx_, r[a], kf->depth_map_.ptr()) != SDM_OK ||
-                sdm_download_pointset(ctx_, r[a], kf->SemiDensePointSets_.ptr()) != SDM_OK)
-                report("SemiDenseReconBlock");
-            depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
-            kf->interKF_depth_flag_ = true;  // PM.cc:306
-        }
+        depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
+        kf->interKF_depth_flag_ = true;  // PM.cc:306
     }
     // keep the stage flags REPLICATED: what the other ranks reconstructed / checked in this pass (their maps live on
     // their GPUs; this rank's copies of those keyframes carry only the flags).  The next pass's plan is derived from

@@ -100,11 +100,20 @@ def plan(n_total, world, rank, n_nbr, neighbours_fn):
     interior = [k for k in own if k not in bset]
     inputs = sorted(need)
     slot = {k: i for i, k in enumerate(inputs)}
+    # K4 of a keyframe whose neighbours are all this rank's own needs nothing from the exchange: it runs BEFORE the wait
+    # (`check_early`), only the others after it (`check_late`) -- with index-local covisibility these are the interior
+    # and the boundary keyframes again
+    oset = set(own)
+    late = [k for k, row in zip(own, nbrs) if any(j not in oset for j in row)]
+    lset = set(late)
+    early = [k for k in own if k not in lset]
     return dict(first=first, count=count, own=own, nbrs=nbrs, inputs=inputs, boundary=boundary,
                 interior=interior, recv=recv, send=send, n_total=n_total, world=world, rank=rank,
                 slot=slot, n_slots=len(inputs), first_slot=slot[first], contrib=contrib, contrib_count=contrib_count,
                 own_slots=[slot[k] for k in own], nbr_slots=[[slot[j] for j in row] for row in nbrs],
-                boundary_slots=[slot[k] for k in boundary], interior_slots=[slot[k] for k in interior])
+                boundary_slots=[slot[k] for k in boundary], interior_slots=[slot[k] for k in interior],
+                check_early=early, check_late=late, check_early_slots=[slot[k] for k in early],
+                check_late_slots=[slot[k] for k in late])
 
 
 def _runs(idx):
@@ -271,7 +280,15 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
     own, nbrs = pl["own_slots"], pl["nbr_slots"]
     nb_of = dict(zip(own, nbrs))
     boundary, interior = pl["boundary_slots"], pl["interior_slots"]
+    early, late = pl["check_early_slots"], pl["check_late_slots"]
     native = transport == "native"
+
+    def check(slots):  # K4 with K5 riding along (PM.cc:300-306); snapshot form: the pool's maps stay as reconstructed
+        if slots:
+            eng.inter_check_pointset(slots, [nb_of[k] for k in slots], commit=False)
+
+    # In every sharded form the keyframes whose K4 reads no other rank's map are checked BEFORE the wait for the exchange
+    # (the transfer has the interior keyframes' K1-K3 and their K4 to hide behind), the others after it.
     if world > 1 and exchange == "halo" and boundary:
         eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
         if native:
@@ -280,11 +297,13 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
             works = exchange_halo_async(pool, pl, group)
         if interior:
             eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
+        check(early)
         if native:
             eng.exchange_wait()
         else:
             wait_all(works)
             eng.mark_depth_present([s for _, s in halo_lists(pl)[1]])
+        check(late)
     elif exchange == "allgather" and (world > 1 or force_pieces):
         # all-gather of the maps that cross ranks: reconstruct the boundary keyframes, start the collective on the
         # engine's exchange stream, reconstruct the interior keyframes meanwhile
@@ -298,12 +317,15 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
             eng.allgather_piece(contrib_slots(pl))
             if rest:
                 eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            check(early)
             eng.allgather_finish(contrib_fetch_list(pl))
         else:
             allgather_boundary(pool, pl, group)
             if rest:
                 eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            check(early)
             eng.mark_depth_present([s for _, s in contrib_fetch_list(pl)])
+        check(late)
     elif exchange == "allgather_full" and native and ag_pieces > 1 and (world > 1 or force_pieces):
         # whole-block all-gather, pipelined: the block is reconstructed in sub-blocks; each one's maps are gathered on
         # the engine's exchange stream while the next one's K1-K3 run (sdm_allgather_begin / _piece / _finish)
@@ -311,8 +333,10 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         for off, cnt in sub_blocks(pl["count"], ag_pieces):
             eng.recon(own[off:off + cnt], nbrs[off:off + cnt], min_d, max_d)
             eng.allgather_piece(own[off:off + cnt])
+        check(early)
         # position in the owner's block == keyframe - owner's first keyframe; owner * count + position == keyframe
         eng.allgather_finish(fetch_list(pl))
+        check(late)
     else:
         eng.recon(own, nbrs, min_d, max_d)
         if world > 1:
@@ -322,4 +346,4 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
                 key = (id(pool), pl["n_total"])
                 _gather_cache[key] = allgather_depth(pool, pl, group, _gather_cache.get(key))
                 eng.mark_depth_present([s for _, s in fetch_list(pl)])
-    eng.inter_check_pointset(own, nbrs, commit=False)  # K4 with K5 riding along (PM.cc:300-306)
+        eng.inter_check_pointset(own, nbrs, commit=False)
