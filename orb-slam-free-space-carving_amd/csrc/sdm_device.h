@@ -375,6 +375,7 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 //        instead of the row clamp
 // bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
 // bit 9  GetFusion's 1/sigma^2 (double) from a float seed and three FMA steps instead of the IEEE double division
+// bits 10, 11 (lost: +2 % / neutral) one exec-mask region per candidate; gate 2's |.| as an AND with a literal
 #ifndef SDM_K1_OPT
 #define SDM_K1_OPT 0x27f
 #endif
