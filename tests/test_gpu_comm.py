@@ -175,6 +175,32 @@ def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("W,H,n_maps", [(9, 11, 5), (16, 9, 40), (33, 31, 3)])
+def test_map_copies_odd_and_many(pkg, gpu_ok, W, H, n_maps):
+    """the packing / fetch copies of the all-gather (k_copy_maps: 16-byte units, <= 32 maps per launch) with an odd pixel
+    count (plain copies), more maps than one launch takes, and non-contiguous lists -- uploaded random maps, bit-equal"""
+    rng = np.random.default_rng(W * 1000 + H)
+    eng = pkg.Engine(W, H, 2 * n_maps + 1, max_neighbours=3)
+    maps = {}
+    src = [2 * i + 1 for i in range(n_maps)]  # every other slot: never a run -> packed through the staging buffer
+    for s_ in src:
+        maps[s_] = (rng.random((H, W), dtype=np.float32), rng.random((H, W), dtype=np.float32))
+        eng.upload_depth(s_, *maps[s_])
+    eng.allgather_begin(n_maps)
+    eng.allgather_piece(src)
+    dst = [2 * i for i in range(n_maps)]
+    perm = list(rng.permutation(n_maps))
+    eng.allgather_finish([(int(perm[i]), dst[i]) for i in range(n_maps)])
+    for i in range(n_maps):
+        r, sg = eng.download_depth(dst[i])
+        assert_bit_equal(r, maps[src[perm[i]]][0], "rho of map %d" % i)
+        assert_bit_equal(sg, maps[src[perm[i]]][1], "sigma of map %d" % i)
+    for s_ in src:  # the sources are untouched
+        r, sg = eng.download_depth(s_)
+        assert_bit_equal(r, maps[s_][0])
+    eng.close()
+
+
 def test_exchange_argument_checks(pkg, gpu_ok):
     eng = pkg.Engine(64, 48, 4, max_neighbours=3)
     with pytest.raises(pkg.SdmError) as e:  # world size 1 has no peers
