@@ -115,7 +115,13 @@ def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
     n = 5
     eng = pkg.Engine(seq.W, seq.H, seq.n_kf + 6, max_neighbours=n)
     seq.upload(eng, device_prepass=True)
-    eng.comm_init(eng.comm_unique_id(), 1, 0)
+    try:
+        eng.comm_init(eng.comm_unique_id(), 1, 0)
+    except pkg.SdmError as e:  # no librccl / no bootstrap interface on this box: an environment matter, not a result
+        eng.close()
+        if e.code != 5:  # SDM_ECOMM
+            raise
+        pytest.skip("RCCL communicator cannot be created here: %s" % e)
     assert eng.comm_info() == (1, 0)
     assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # ncclAllReduce(min)
     refs = list(range(seq.n_kf))
