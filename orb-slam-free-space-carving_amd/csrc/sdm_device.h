@@ -376,7 +376,6 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
 // bit 9  GetFusion's 1/sigma^2 (double) from a float seed and three FMA steps instead of the IEEE double division
 // bits 10, 11 (lost: +2 % / neutral) one exec-mask region per candidate; gate 2's |.| as an AND with a literal
-// bit 12 (lost: +2.4 %, 8 spilled VGPRs) wave-uniform scan loop with a two-slot last batch
 #ifndef SDM_K1_OPT
 #define SDM_K1_OPT 0x27f
 #endif
@@ -492,90 +491,6 @@ struct ScanState {
 // (H-2)*W + W+2 < H*W, so every address stays inside the neighbour's plane without a column clamp.
 // CLEAN: every angle is in [0,360] (PairConst::clean), so d2, d3 are in [-360,360] and the closed-form gates hold for
 // every candidate; otherwise a candidate with d >= gate_lim (or NaN) takes the reference statement.
-template <int NB, bool STATS, bool CLEAN>
-__device__ __forceinline__ void scan_batch(const char* __restrict__ nbase, unsigned W16, float hlim_b, int u0, float u0f,
-                                           int hi, float ab, float cb, float pixel, float grad1, float th_line,
-                                           float ang_pi_rot, float gate_lim, const DevParams& prm, ScanState& S,
-                                           SearchStats* st)
-{
-#if !(SDM_K1_OPT & 0x01)
-    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
-#endif
-    float yfs[NB];
-    unsigned long long rowok[NB];  // lane masks taken before the loads: scalar registers, not VGPRs
-    v4f rs[NB];
-    const unsigned c0 = (unsigned)u0 << 4;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
-        float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
-#if SDM_K1_OPT & 0x01
-        const unsigned off = __umul24((unsigned)(int)yc, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
-        const char* __restrict__ nb_k = nbase + 16 * k;
-#else
-        unsigned uc16 = min(c0 + 16u * k, hi16);                    // min(uj, hi) * 16
-        unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
-        const char* __restrict__ nb_k = nbase;
-#endif
-        yfs[k] = yf;
-        rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
-#if SDM_ABLATE == 5
-        rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
-#else
-        rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
-#endif
-    }
-    // keep each record one 16-byte gather issued here: without this hipcc splits the first record
-    // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
-#pragma unroll
-    for (int k = 0; k < NB; k++)
-        asm volatile("" : "+v"(rs[k]));
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        const int uj = u0 + k;
-        if (STATS && uj <= hi) st->candidates++;
-        const float yf = yfs[k];
-        const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
-        if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
-        if (r.x < prm.lambdaG) continue;                            // PM.cc:411
-#if SDM_ABLATE == 4
-        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-        continue;
-#endif
-        const float d2 = r.y - th_line;     // PM.cc:415-416
-        const float d3 = r.y - ang_pi_rot;  // PM.cc:427
-#if SDM_K1_OPT & 0x04
-        bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
-#else
-        bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
-#endif
-        if (!CLEAN) {
-            if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
-                fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
-        }
-        if (fail) continue;  // PM.cc:421,431
-        if (STATS) st->gate_pass++;
-#if SDM_ABLATE == 3 || SDM_ABLATE == 4
-        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-        continue;
-#endif
-        const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
-        float pe = pixel - rec_lerp_im_w(r, y0w);          // PM.cc:433
-        float ge = grad1 - rec_lerp_grad_w(r, y0w);        // PM.cc:434
-#if SDM_K1_OPT & 0x08
-        float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
-#else
-        float err = match_cost(pe * pe, ge * ge, prm);
-#endif
-        if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
-            S.best_pixel = uj;
-            S.old_err = err;
-            S.best_pe = pe;
-            S.best_ge = ge;
-        }
-    }
-}
-
 template <bool STATS, bool CLEAN>
 __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int W, int H, int lo, int hi, float ab,
                                              float cb, float pixel, float grad1, float th_line, float ang_pi_rot,
@@ -585,10 +500,85 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
     // integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3 in one comparison
     const float hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
     const unsigned W16 = (unsigned)W << 4;  // record pitch in bytes (< 2^24)
+#if !(SDM_K1_OPT & 0x01)
+    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
+#endif
     float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
-    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL)
-        scan_batch<SCAN_UNROLL, STATS, CLEAN>(nbase, W16, hlim_b, u0, u0f, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot,
-                                              gate_lim, prm, S, st);
+    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
+        float yfs[SCAN_UNROLL];
+        unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
+        v4f rs[SCAN_UNROLL];
+        const unsigned c0 = (unsigned)u0 << 4;
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+            float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
+            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
+#if SDM_K1_OPT & 0x01
+            const unsigned off = __umul24((unsigned)(int)yc, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
+            const char* __restrict__ nb_k = nbase + 16 * k;
+#else
+            unsigned uc16 = min(c0 + 16u * k, hi16);                    // min(uj, hi) * 16
+            unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
+            const char* __restrict__ nb_k = nbase;
+#endif
+            yfs[k] = yf;
+            rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
+#if SDM_ABLATE == 5
+            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
+#else
+            rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
+#endif
+        }
+        // keep each record one 16-byte gather issued here: without this hipcc splits the first record
+        // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++)
+            asm volatile("" : "+v"(rs[k]));
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; k++) {
+            const int uj = u0 + k;
+            if (STATS && uj <= hi) st->candidates++;
+            const float yf = yfs[k];
+            const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
+            if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
+            if (r.x < prm.lambdaG) continue;                            // PM.cc:411
+#if SDM_ABLATE == 4
+            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+            continue;
+#endif
+            const float d2 = r.y - th_line;     // PM.cc:415-416
+            const float d3 = r.y - ang_pi_rot;  // PM.cc:427
+#if SDM_K1_OPT & 0x04
+            bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
+#else
+            bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+#endif
+            if (!CLEAN) {
+                if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
+                    fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
+            }
+            if (fail) continue;  // PM.cc:421,431
+            if (STATS) st->gate_pass++;
+#if SDM_ABLATE == 3 || SDM_ABLATE == 4
+            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+            continue;
+#endif
+            const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
+            float pe = pixel - rec_lerp_im_w(r, y0w);          // PM.cc:433
+            float ge = grad1 - rec_lerp_grad_w(r, y0w);        // PM.cc:434
+#if SDM_K1_OPT & 0x08
+            float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
+#else
+            float err = match_cost(pe * pe, ge * ge, prm);
+#endif
+            if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
+                S.best_pixel = uj;
+                S.old_err = err;
+                S.best_pe = pe;
+                S.best_ge = ge;
+            }
+        }
+    }
 }
 
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
