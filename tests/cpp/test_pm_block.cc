@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include "sdm/ProbabilityMapping.h"
+#include "sdm_c.h"
 
 static void rd(FILE* f, void* p, size_t n)
 {
@@ -63,7 +64,17 @@ int main(int argc, char** argv)
     ProbabilityMapping pm(&map, opt);
     pm.SemiDenseReconBlock(map.keyframes, 0, n_kf);  // sizes the context, runs K1-K5 for the block
     if (!pm.ok()) return 3;
-    if (!pm.InitSharding(nullptr, 1, 0)) return 4;   // world size 1: accepted, nothing to build
+    // world size 1: accepted, nothing to build -- unless SDM_COMM_SINGLE_RANK_RCCL=1 asks for a real one-rank RCCL
+    // communicator (the hardware rehearsal): then the second pass runs its go / no-go all-reduce and an empty send/recv
+    // group through RCCL, from the C++ class
+    unsigned char comm_id[SDM_COMM_ID_BYTES];
+    const unsigned char* idp = nullptr;
+    const char* rehearse = getenv("SDM_COMM_SINGLE_RANK_RCCL");
+    if (rehearse && atoi(rehearse) == 1) {
+        if (sdm_comm_unique_id(comm_id) != SDM_OK) return 6;  // no RCCL here
+        idp = comm_id;
+    }
+    if (!pm.InitSharding(idp, 1, 0)) return idp ? 6 : 4;
     pm.SemiDenseReconBlock(map.keyframes, 0, n_kf);  // second pass: everything already reconstructed -> no work, no change
 
     // slot-cache contract

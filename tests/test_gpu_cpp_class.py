@@ -219,3 +219,11 @@ def test_cpp_class_block_driver_matches_oracle_snapshot(pkg, oracle, gpu_ok, tmp
         assert_bit_equal(got, oracle.pointset(seq.okf[k], chk), "SemiDensePointSets_ kf %d" % k)
         kept += int((chk > 1e-6).sum())
     assert kept > 1000
+    # once more with a real one-rank RCCL communicator inside the class (the go / no-go all-reduce and the empty send/recv
+    # group of the second pass run through RCCL): same bytes out.  Exit code 6 = no communicator can be created here.
+    out2 = tmp_path / "out_rccl.bin"
+    r = subprocess.run([exe, str(blob), str(out2), str(tmp_path / "cloud2.obj")],
+                       env=dict(os.environ, SDM_COMM_SINGLE_RANK_RCCL="1"))
+    if r.returncode != 6:
+        assert r.returncode == 0
+        assert np.array_equal(np.fromfile(out2, dtype=np.uint8), raw)
