@@ -5,8 +5,9 @@
 //   pool  float2[P]    8 B/px  depth map {rho, sigma}  = kf->depth_map_/depth_sigma_     (K1-K3)
 //   chk   float [P]    4 B/px  inter-keyframe-checked rho                                 (K4)
 //   xyz   float [3P]  12 B/px  SemiDensePointSets_ (optional)                             (K5)
-// plus one scratch pool of batch_capacity slots for the Jacobi stencil passes (K2 writes scratch,
-// K3 writes back), one staging keyframe for uploads, and the per-batch constant tables.
+// plus one scratch pool of batch_capacity slots for the Jacobi stencil passes (arbitrary maps: K2 writes scratch planes,
+// K3 writes back; pipeline maps: K2's results compactly by list position, then committed -- sdm_kernels.h), one staging
+// keyframe for uploads, and the per-batch constant tables.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -71,6 +72,12 @@ struct sdm_ctx {
     unsigned open_capacity = 0;
     unsigned open_quota = 512;
     unsigned open_launch = 0;
+    // K3's candidate list on pipeline maps (listed pixels with rho < 1e-6 and a non-zero sigma; normally empty)
+    unsigned* d_grow_ctr = nullptr;  // two counters, used alternately by successive K2 launches
+    long long* d_grow_pix = nullptr;
+    float2* d_grow_val = nullptr;
+    unsigned grow_capacity = 0;
+    unsigned grow_launch = 0;
     unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
     int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
@@ -606,6 +613,14 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         const unsigned init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
         if (hipMemcpy(c->d_open_ctr, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(SDM_EHIP, "open-list counter initialisation failed"));
+        long long gcap = std::min<long long>(1ll << 18, c->P);
+        if (const char* e = getenv("SDM_GROW_CAPACITY")) gcap = std::max<long long>(1, std::min<long long>(gcap, atoll(e)));  // tests
+        c->grow_capacity = (unsigned)gcap;
+        if ((rc = dev_alloc(&c->d_grow_ctr, 2)) || (rc = dev_alloc(&c->d_grow_pix, (size_t)gcap)) ||
+            (rc = dev_alloc(&c->d_grow_val, (size_t)gcap)))
+            return bail(rc);
+        if (hipMemset(c->d_grow_ctr, 0, 2 * sizeof(unsigned)) != hipSuccess)
+            return bail(fail(SDM_EHIP, "grow-list counter initialisation failed"));
     }
     if ((rc = dev_alloc(&c->d_chunk, (size_t)((c->P + ACT_BLOCK - 1) / ACT_BLOCK)))) return bail(rc);
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
@@ -676,6 +691,9 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_open_pix);
     (void)hipFree(c->d_open_vm);
     (void)hipFree(c->d_open_hyp);
+    (void)hipFree(c->d_grow_ctr);
+    (void)hipFree(c->d_grow_pix);
+    (void)hipFree(c->d_grow_val);
     (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_rgb);
@@ -991,6 +1009,44 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
             max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[first + r]] + BLOCK - 1) / BLOCK);
         if (max_chunks == 0) continue;
         const int per_ref = 8 * ((max_chunks + 7) / 8);
+#if SDM_INTRA_COMPACT
+        // K2 -> compact results (the scratch memory, indexed by list position) -> commit into the pool; K3 = the (normally
+        // empty) candidate list K2 collected, grown by one small launch, reads before writes (sdm_kernels.h)
+        GrowList gl;
+        gl.count = c->d_grow_ctr + (c->grow_launch & 1u);
+        gl.next = c->d_grow_ctr + ((c->grow_launch + 1u) & 1u);
+        gl.capacity = c->grow_capacity;
+        gl.pix = c->d_grow_pix;
+        gl.val = c->d_grow_val;
+        for_ref_slices(count, per_ref, BLOCK, [&](int f, int cn) {
+            if (check && grow)
+                hipLaunchKernelGGL((k_intra_compact<true, true>), dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->pool,
+                                   c->scratch, c->d_off, c->d_off + K, c->d_refs, first + f, cn, c->W, max_chunks, c->P,
+                                   c->d_act, gl);
+            else if (check)
+                hipLaunchKernelGGL((k_intra_compact<true, false>), dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->pool,
+                                   c->scratch, c->d_off, c->d_off + K, c->d_refs, first + f, cn, c->W, max_chunks, c->P,
+                                   c->d_act, gl);
+            else
+                hipLaunchKernelGGL((k_intra_compact<false, true>), dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->pool,
+                                   c->scratch, c->d_off, c->d_off + K, c->d_refs, first + f, cn, c->W, max_chunks, c->P,
+                                   c->d_act, gl);
+        });
+        HIP_TRY(hipGetLastError());
+        if (check) {
+            for_ref_slices(count, per_ref, BLOCK, [&](int f, int cn) {
+                hipLaunchKernelGGL(k_intra_commit, dim3(per_ref * cn), dim3(BLOCK), 0, c->stream, c->pool, c->scratch, c->d_off,
+                                   c->d_off + K, c->d_refs, first + f, cn, c->W, max_chunks, c->P, c->d_act);
+            });
+            HIP_TRY(hipGetLastError());
+        }
+        if (grow) {
+            hipLaunchKernelGGL(k_grow, dim3(1), dim3(GROW_BLOCK), 0, c->stream, c->pool, gl, c->W, c->P, c->scratch, c->d_off,
+                               c->d_off + K, c->d_refs, first, count, c->d_act);
+            HIP_TRY(hipGetLastError());
+            c->grow_launch++;
+        }
+#else
         if (check) {
             // K2 writes every listed pixel of the scratch planes, and K3's list kernel substitutes zeros for
             // neighbours outside the list instead of reading them, so the planes need no clearing -- unless the
@@ -1019,6 +1075,7 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
                 HIP_TRY(hipMemcpyAsync(c->pool + c->h_off[first + r], c->scratch + (long long)r * c->P,
                                        sizeof(float2) * c->P, hipMemcpyDeviceToDevice, c->stream));
         }
+#endif
     }
     return SDM_OK;
 }

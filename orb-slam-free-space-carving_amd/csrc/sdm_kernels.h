@@ -19,6 +19,9 @@ constexpr int TILE_W = 64;
 constexpr int TILE_H = 16;
 constexpr int TILE_PX = TILE_W * TILE_H;  // 1024
 constexpr int BLOCK = 256;
+#ifndef SDM_INTRA_COMPACT
+#define SDM_INTRA_COMPACT 1  // K2/K3 on pipeline maps through a compact result array (0: through a scratch plane, the round-2 form)
+#endif
 constexpr int PX_PER_THREAD = TILE_PX / BLOCK;  // 4
 
 struct TileGeom {
@@ -1108,6 +1111,144 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
         if (gt_1em6(c.x)) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
     }
     out[y * W + x] = o;
+}
+
+// ---- K2 + K3 on pipeline maps without a second plane ---------------------------------------------------------------------
+// The list kernels above go pool -> scratch plane -> pool: four sparse passes (8-byte gathers / scatters at list pixels, ~20
+// cache lines per wave instruction), and what bounds them is the number of line misses a CU keeps in flight.  Here K2
+// writes its result COMPACTLY, indexed by list position (`out[r][t]`, 4 lines per wave instruction), a commit pass reads
+// that back and scatters it into the pool (the Jacobi order is kept: every K2 read of the pool precedes every write), and
+// K3 is reduced to what it really is on pipeline maps -- nothing, except for listed pixels that hold rho < 1e-6 WITH a
+// non-zero sigma (PM.cc:560; sigma_p = 0 can never grow): K2 appends those to a (normally empty) list and
+// one small kernel grows them, reads before writes.  Two sparse passes instead of four.
+struct GrowList {
+    unsigned* count;            // [0] candidates seen by this call's K2
+    unsigned* next;             // the other call's counter, re-zeroed by k_grow
+    unsigned capacity;          // entries of pix / val; beyond it the grow kernels walk the keyframes' whole lists instead
+    long long* pix;             // pool index (slot * plane + y * W + x)
+    float2* val;
+};
+// CHECK: run IntraKeyFrameDepthChecking (else the value passes through); DETECT: append K3's candidates
+template <bool CHECK, bool DETECT>
+__global__ __launch_bounds__(BLOCK) void k_intra_compact(const float2* __restrict__ pool, float2* __restrict__ out_base,
+                                                         const long long* __restrict__ pool_off,
+                                                         const long long* __restrict__ out_off,
+                                                         const RefConst* __restrict__ refs, int first, int n_ref, int W,
+                                                         int max_chunks, long long plane, const unsigned* __restrict__ act,
+                                                         GrowList gl)
+{
+    const int b = blockIdx.x;
+    const int i8 = b >> 3;
+    const int cl = i8 / n_ref;
+    const int r = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
+    const RefConst rc = refs[first + r];
+    const int t = chunk * BLOCK + threadIdx.x;
+    const bool on = t < rc.act_count;
+    float2 o = make_float2(0.f, 0.f);
+    long long pix = 0;
+    if (on) {
+        const unsigned xy = act[(long long)rc.slot * plane + t];
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        const float2* __restrict__ in = pool + pool_off[first + r];
+        const float2 c = in[y * W + x];
+        o = c;
+        if (CHECK && gt_1em6(c.x)) o = intra_check_pixel(in, W, x, y, c);  // PM.cc:497
+        if (CHECK) out_base[out_off[first + r] + t] = o;
+        pix = pool_off[first + r] + y * W + x;
+    }
+    if (DETECT) {
+        // PM.cc:560 (the gradient gate is the list) and the sigma_p = 0 exit of intra_grow_pixel
+        const bool cand = on && lt_1em6(o.x) && !(o.y == 0.0f);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (m != 0ull) {  // rare: one counter add per wave
+            unsigned base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(&gl.count[0], (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (cand) {
+                const unsigned e = base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+                if (e < gl.capacity) gl.pix[e] = pix;
+            }
+        }
+    }
+}
+
+// compact K2 results -> pool (every listed pixel)
+__global__ __launch_bounds__(BLOCK) void k_intra_commit(float2* __restrict__ pool, const float2* __restrict__ in_base,
+                                                        const long long* __restrict__ pool_off,
+                                                        const long long* __restrict__ in_off,
+                                                        const RefConst* __restrict__ refs, int first, int n_ref, int W,
+                                                        int max_chunks, long long plane, const unsigned* __restrict__ act)
+{
+    const int b = blockIdx.x;
+    const int i8 = b >> 3;
+    const int cl = i8 / n_ref;
+    const int r = i8 - cl * n_ref;
+    const int chunk = cl * 8 + (b & 7);
+    if (chunk >= max_chunks) return;
+    const RefConst rc = refs[first + r];
+    const int t = chunk * BLOCK + threadIdx.x;
+    if (t >= rc.act_count) return;
+    const unsigned xy = act[(long long)rc.slot * plane + t];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    pool[pool_off[first + r] + y * W + x] = in_base[in_off[first + r] + t];
+}
+
+// K3 for the candidates: ONE workgroup (launched after the commit), so that "every read before any write" is a
+// __syncthreads() -- phase 1 computes the grown values from the pool (K2's committed output; the pool is zero outside the
+// lists, which is what the list form's "neighbours outside the list count as zero" means), phase 2 stores them.  With no
+// candidate -- every launch on real data -- it costs one empty launch.  List overflow (count > capacity): walk every listed
+// pixel of the batch [first, first + n_ref) instead and keep the values in the compact array.  Also re-zeroes the counter
+// the NEXT call's K2 appends to.
+constexpr int GROW_BLOCK = 1024;
+__global__ __launch_bounds__(GROW_BLOCK) void k_grow(float2* __restrict__ pool, GrowList gl, int W, long long plane,
+                                                     float2* __restrict__ cmp_base, const long long* __restrict__ pool_off,
+                                                     const long long* __restrict__ cmp_off,
+                                                     const RefConst* __restrict__ refs, int first, int n_ref,
+                                                     const unsigned* __restrict__ act)
+{
+    const unsigned total = gl.count[0];
+    if (threadIdx.x == 0) gl.next[0] = 0u;
+    if (total == 0u) return;
+    const bool listed = total <= gl.capacity;
+    if (listed) {
+        for (long long g = threadIdx.x; g < (long long)total; g += GROW_BLOCK) {
+            const long long pix = gl.pix[g];
+            const long long base = pix / plane * plane;
+            const int p = (int)(pix - base);
+            const int y = p / W, x = p - y * W;
+            gl.val[g] = intra_grow_pixel<false>(pool + base, W, x, y, pool[pix]);
+        }
+    } else {
+        for (int r = 0; r < n_ref; r++) {
+            const RefConst rc = refs[first + r];
+            const float2* __restrict__ in = pool + pool_off[first + r];
+            for (long long t = threadIdx.x; t < rc.act_count; t += GROW_BLOCK) {
+                const unsigned xy = act[(long long)rc.slot * plane + t];
+                const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+                const float2 c = in[y * W + x];
+                float2 o = c;
+                if (lt_1em6(c.x) && !(c.y == 0.0f)) o = intra_grow_pixel<false>(in, W, x, y, c);
+                cmp_base[cmp_off[first + r] + t] = o;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();  // every read of the pool above precedes every write below (Jacobi, PM.cc:551-552, 594-595)
+    if (listed) {
+        for (long long g = threadIdx.x; g < (long long)total; g += GROW_BLOCK) pool[gl.pix[g]] = gl.val[g];
+    } else {
+        for (int r = 0; r < n_ref; r++) {
+            const RefConst rc = refs[first + r];
+            float2* __restrict__ out = pool + pool_off[first + r];
+            for (long long t = threadIdx.x; t < rc.act_count; t += GROW_BLOCK) {
+                const unsigned xy = act[(long long)rc.slot * plane + t];
+                const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+                out[y * W + x] = cmp_base[cmp_off[first + r] + t];  // unchanged for everything that was no candidate
+            }
+        }
+    }
 }
 
 // ---- K4: InterKeyFrameDepthChecking, PM.cc:628-799 ------------------------------------------------------

@@ -228,9 +228,14 @@ def test_intra_check_and_grow_maps(pkg, oracle, gpu_ok, shape):
     eng.close()
 
 
-def test_list_kernels_on_declared_pipeline_maps(pkg, oracle, gpu_ok, seq_mid):
+@pytest.mark.parametrize("grow_list", ["default", "tiny"])
+def test_list_kernels_on_declared_pipeline_maps(pkg, oracle, gpu_ok, seq_mid, grow_list, monkeypatch):
     """K2/K3/K4 list kernels (one thread per active-list entry) on crafted maps that are zero outside
-    the active set but otherwise adversarial: NaN/Inf/zero sigma, rho~0 with sigma>0 (growing live)"""
+    the active set but otherwise adversarial: NaN/Inf/zero sigma, rho~0 with sigma>0 (growing live).  K3 on lists is a
+    candidate list collected by K2 (or by a detection pass) and grown by two small kernels; "tiny" = a 4-entry list, so
+    the grow kernels fall back to walking the whole lists."""
+    if grow_list == "tiny":
+        monkeypatch.setenv("SDM_GROW_CAPACITY", "4")
     seq, n = seq_mid, 7
     eng = make_engine(pkg, seq, n)
     rng = np.random.default_rng(21)
