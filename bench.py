@@ -63,6 +63,9 @@ def parse():
                          "overlapped with the reconstruction of the interior ones); allgather_full = every rank's whole "
                          "block, pipelined in sub-blocks (BASELINE.json's literal wording, 3x the bytes); halo = "
                          "point-to-point.  The other forms are timed too: exchange_ms_per_step, value_<form>")
+    ap.add_argument("--wire", default="compact", choices=["compact", "whole"],
+                    help="native transport: what crosses ranks per depth map -- the {rho,sigma} of the keyframe's active-list "
+                         "entries (the map is zero elsewhere; the receiver holds the same list), or the whole map")
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="N>1: RCCL called by the engine's C ABI (sdm_exchange_*) or torch.distributed on the pool tensor")
     ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (SURVEY.md §8d adversarial set)")
@@ -87,12 +90,12 @@ def self_launch(args):
 
 
 def source_hash():
-    """hash of the kernel sources: ties a committed PMC traffic figure to the build it was measured on"""
+    """hash of the kernel sources (device code: sdm_device.h, sdm_kernels.h): ties a committed PMC traffic figure to the
+    kernels it was measured on; the host side of the engine and the exchange (sdm_engine.hip, sdm_comm.h) are not part of it"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "orb-slam-free-space-carving_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("sdm_device.h", "sdm_kernels.h"):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -384,6 +387,7 @@ def main():
     arch = eng.arch()
     exchanging = world > 1 and not args.independent
     transport_note = None
+    wire_entries = 0
     if exchanging and transport == "native":
         # the engine's own RCCL communicator (include/sdm_c.h sdm_comm_init) and one exchange of each form as a
         # self-check.  If any rank fails (library, communicator or transfer error) ALL ranks agree -- over the
@@ -401,10 +405,14 @@ def main():
             ok, why = 0, repr(e)
         if agreed(ok):  # every rank holds a communicator: only now may anyone post a transfer
             try:
+                if args.wire == "compact":
+                    wire_entries = pkg.shard.agree_compact_wire(eng, pl)  # one all-reduce; the same value on every rank
                 wl.step("halo", "native")
                 wl.step("allgather", "native")
                 wl.step("allgather_full", "native")
                 torch.cuda.synchronize()
+                if wire_entries > 0 and eng.exchange_mismatches():
+                    raise RuntimeError("compact wire format: a received keyframe's active list differs from the sender's")
             except Exception as e:  # noqa: BLE001
                 ok, why = 0, repr(e)
             ok = 1 if agreed(ok) else 0
@@ -453,6 +461,11 @@ def main():
             dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
             others[other] = reduce_max(dt2)
             exchange_ms[other] = round(others[other] / args.steps * 1e3, 4)
+        if wire_entries > 0:  # and the default form once more with WHOLE maps on the wire, for comparison
+            eng.exchange_compact(0)
+            dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, args.exchange, transport)
+            exchange_ms[args.exchange + ", whole maps on the wire"] = round(reduce_max(dt2) / args.steps * 1e3, 4)
+            eng.exchange_compact(wire_entries)
 
     if rank != 0:
         eng.close()
@@ -515,6 +528,11 @@ def main():
         out["config"]["exchange_maps_per_rank"] = {  # maps every rank RECEIVES per step
             "allgather": (world - 1) * pl["contrib_count"], "allgather_full": (world - 1) * pl["count"],
             "halo": sum(len(v) for v in pl["recv"].values())}
+        out["config"]["exchange_wire"] = (
+            {"format": "{rho,sigma} of the keyframe's active-list entries (sdm_exchange_compact); the receiver scatters them "
+                       "through its own list of that keyframe", "entries_per_map": wire_entries,
+             "bytes_per_map": 8 * wire_entries, "whole_map_bytes": 8 * P}
+            if wire_entries > 0 else {"format": "whole maps", "bytes_per_map": 8 * P})
     if transport_note:
         out["transport_note"] = transport_note
     if rehearse:

@@ -206,6 +206,23 @@ int sdm_allgather_depth(sdm_ctx *ctx, int first_slot, int count, int n_fetch, co
 int sdm_allgather_begin(sdm_ctx *ctx, int maps_per_rank);
 int sdm_allgather_piece(sdm_ctx *ctx, int count, const int *slots);
 int sdm_allgather_finish(sdm_ctx *ctx, int n_fetch, const int *fetch_index, const int *dst_slot);
+/* Wire format of the maps that cross ranks in sdm_exchange_halo[_begin] and sdm_allgather_piece / _finish.
+ * entries_per_map = 0 (default): whole maps, 8*W*H bytes each.  > 0: the {rho,sigma} of the first entries_per_map entries
+ * of the keyframe's active-pixel list (the pixels that pass the gradient gate, PM.cc:201), in list order -- all a
+ * reconstructed map holds, since it is zero elsewhere: 8*entries_per_map bytes (a fifth of the map on typical images).
+ * The receiver scatters them through ITS list of that keyframe, which it has because the keyframe is part of its input
+ * halo (SDM_ESTATE if the destination slot holds no keyframe).  Every rank must set the same value, at least the longest
+ * list (sdm_active_count) among the keyframes it sends or receives; a call that meets a longer one fails with SDM_ESTATE
+ * before posting anything -- so agree on the value across ranks beforehand (bench.py: an all-reduce(max) at set-up).
+ * sdm_allgather_depth (the one-shot form) always moves whole maps and refuses to run while entries_per_map > 0.
+ * sdm_comm_destroy resets the format to whole maps. */
+int sdm_exchange_compact(sdm_ctx *ctx, int entries_per_map);
+/* Every compact map carries its sender's list length; a receiver whose list of that keyframe has another length (its
+ * image differs from the sender's) leaves the destination plane as it is instead of scattering onto wrong pixels, and
+ * counts the event.  *count = such maps since the last call (host-blocking; 0 on a healthy job). */
+int sdm_exchange_mismatches(sdm_ctx *ctx, int *count);
+/* Length of the slot's active-pixel list under the current lambdaG (built now if need be; host-blocking). */
+int sdm_active_count(sdm_ctx *ctx, int slot, int *count);
 /* Go / no-go before a collective pass: all ranks call it; *all_ok = min over ranks of local_ok (host-blocking).
  * A rank that cannot take part in the exchange it planned reports it here, so peers skip the pass instead of
  * waiting for transfers that never come. */

@@ -86,6 +86,9 @@ SYMBOLS = [
     ("sdm_allgather_piece", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_allgather_finish", C.c_int, [_ctx, C.c_int, _ip, _ip]),
     ("sdm_comm_all_ok", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_exchange_compact", C.c_int, [_ctx, C.c_int]),
+    ("sdm_exchange_mismatches", C.c_int, [_ctx, _ip]),
+    ("sdm_active_count", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_intra_grow_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_epipolar_search", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -392,6 +395,20 @@ class Engine:
         fi, fip = _i32([i for i, _ in fetch])
         ds, dsp = _i32([s for _, s in fetch])
         self._check(self.lib.sdm_allgather_finish(self.ctx, len(fetch), fip, dsp))
+
+    def exchange_compact(self, entries_per_map):
+        """0 = whole maps cross ranks; > 0 = the {rho,sigma} of the first entries_per_map active-list entries"""
+        self._check(self.lib.sdm_exchange_compact(self.ctx, int(entries_per_map)))
+
+    def exchange_mismatches(self):
+        out = C.c_int()
+        self._check(self.lib.sdm_exchange_mismatches(self.ctx, C.byref(out)))
+        return int(out.value)
+
+    def active_count(self, slot):
+        out = C.c_int()
+        self._check(self.lib.sdm_active_count(self.ctx, int(slot), C.byref(out)))
+        return int(out.value)
 
     def comm_all_ok(self, local_ok=True):
         out = C.c_int()

@@ -110,6 +110,9 @@ void comm_release(sdm_ctx* c)
     (void)hipFree(c->stage_buf);
     c->stage_buf = nullptr;
     c->stage_slots = 0;
+    (void)hipFree(c->d_xchg_mismatch);
+    c->d_xchg_mismatch = nullptr;
+    c->xchg_entries = 0;
     c->xchg_pending = false;
     c->ag_open = false;
     c->ag_pieces.clear();
@@ -147,6 +150,144 @@ int copy_maps(sdm_ctx* c, int n, const float2* const* src, float2* const* dst, h
         }
         hipLaunchKernelGGL(k_copy_maps, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, n16);
         HIP_TRY(hipGetLastError());
+    }
+    return SDM_OK;
+}
+
+// ---- compact transport (sdm_exchange_compact) ---------------------------------------------------------------------------
+// A reconstructed map is zero outside its keyframe's active-pixel list (PM.cc:201), and a rank that reads another rank's
+// map holds that keyframe's image -- hence the same list -- as part of its input halo.  So a map can cross ranks as the
+// {rho,sigma} of its list entries, in list order: ~19 % of the pixels on the App. D scene, a fixed `entries` per map on the
+// wire (the list's tail is padding).  Sender: k_pack_lists gathers them; receiver: k_unpack_lists scatters them through
+// ITS list into a plane that is (or is first made) zero elsewhere.
+// A packed map is `entries` values followed by a header (XCHG_HEADER float2, one cache line): the sender's list length.
+// A receiver whose list of that keyframe has another length (its image differs from the sender's) does not scatter the
+// map -- it would land on the wrong pixels -- and counts the mismatch (sdm_exchange_mismatches).
+constexpr int XCHG_HEADER = 8;
+struct ListBatch {
+    int slot[COPY_BATCH];
+    float2* buf[COPY_BATCH];
+};
+__global__ __launch_bounds__(BLOCK) void k_pack_lists(ListBatch b, const float2* __restrict__ pool, long long plane, int W,
+                                                      const unsigned* __restrict__ act, const int* __restrict__ act_count,
+                                                      int entries)
+{
+    const int slot = b.slot[blockIdx.y];
+    float2* __restrict__ out = b.buf[blockIdx.y];
+    const int n = act_count[slot];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[entries] = make_float2(__int_as_float(n), 0.0f);
+    const unsigned* __restrict__ list = act + (long long)slot * plane;
+    const float2* __restrict__ map = pool + (long long)slot * plane;
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n; t += gridDim.x * BLOCK) {
+        const unsigned xy = list[t];
+        out[t] = map[(int)(xy >> 16) * W + (int)(xy & 0xffffu)];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_unpack_lists(ListBatch b, float2* __restrict__ pool, long long plane, int W,
+                                                        const unsigned* __restrict__ act, const int* __restrict__ act_count,
+                                                        int entries, unsigned* __restrict__ mismatches)
+{
+    const int slot = b.slot[blockIdx.y];
+    const float2* __restrict__ in = b.buf[blockIdx.y];
+    const int n = act_count[slot];
+    if (__float_as_int(in[entries].x) != n) {  // the same for every thread of the map
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+        return;
+    }
+    const unsigned* __restrict__ list = act + (long long)slot * plane;
+    float2* __restrict__ map = pool + (long long)slot * plane;
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n; t += gridDim.x * BLOCK) {
+        const unsigned xy = list[t];
+        map[(int)(xy >> 16) * W + (int)(xy & 0xffffu)] = in[t];
+    }
+}
+int list_kernel(sdm_ctx* c, bool pack, int n, const int* slots, float2* const* bufs, hipStream_t stream)
+{
+    const unsigned gx = (unsigned)std::min<long long>(((long long)c->xchg_entries + BLOCK - 1) / BLOCK, 256);
+    for (int first = 0; first < n; first += COPY_BATCH) {
+        const int m = std::min(COPY_BATCH, n - first);
+        ListBatch b;
+        for (int i = 0; i < COPY_BATCH; i++) {
+            b.slot[i] = slots[first + (i < m ? i : 0)];
+            b.buf[i] = bufs[first + (i < m ? i : 0)];
+        }
+        if (pack)
+            hipLaunchKernelGGL(k_pack_lists, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, c->pool, c->P, c->W, c->d_act,
+                               c->d_act_count, c->xchg_entries);
+        else
+            hipLaunchKernelGGL(k_unpack_lists, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, c->pool, c->P, c->W, c->d_act,
+                               c->d_act_count, c->xchg_entries, c->d_xchg_mismatch);
+        HIP_TRY(hipGetLastError());
+    }
+    return SDM_OK;
+}
+// the slots whose maps leave in compact form: reconstructed here under the current lambdaG (zero outside the list), and the
+// list fits the wire format
+int check_compact_sources(sdm_ctx* c, int n, const int* slots)
+{
+    int rc = sync_counts(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        if (!(c->recon_lambdaG[slots[i]] == c->dprm.lambdaG) || !(c->act_lambdaG[slots[i]] == c->dprm.lambdaG))
+            return fail(SDM_ESTATE, "compact exchange: a source map is not a pipeline map (zero outside its active list)");
+        if (c->h_act_count[slots[i]] > c->xchg_entries)
+            return fail(SDM_ESTATE, "compact exchange: a source keyframe's active list is longer than entries_per_map");
+    }
+    return SDM_OK;
+}
+// the slots that receive compact maps: the keyframe (image -> list) must be resident; the plane is zeroed first unless it
+// already is zero outside the list.  `stream` is the exchange stream, ordered behind everything queued so far.
+int prepare_compact_destinations(sdm_ctx* c, int n, const int* slots, hipStream_t stream)
+{
+    int rc;
+    bool built = false;
+    for (int i = 0; i < n; i++) {
+        if ((rc = check_slot(c, slots[i], true))) return rc;
+        if (!(c->act_lambdaG[slots[i]] == c->dprm.lambdaG)) {
+            if ((rc = build_active(c, slots[i]))) return rc;
+            built = true;
+        }
+    }
+    if (built) HIP_TRY(hipStreamSynchronize(c->stream));  // first use only: the lists must exist before the exchange stream reads them
+    if ((rc = sync_counts(c))) return rc;
+    for (int i = 0; i < n; i++) {
+        if (c->h_act_count[slots[i]] > c->xchg_entries)
+            return fail(SDM_ESTATE, "compact exchange: a destination keyframe's active list is longer than entries_per_map");
+        if (!(c->recon_lambdaG[slots[i]] == c->dprm.lambdaG))
+            HIP_TRY(hipMemsetAsync(c->pool + (long long)slots[i] * c->P, 0, sizeof(float2) * c->P, stream));
+    }
+    return SDM_OK;
+}
+void mark_received(sdm_ctx* c, int slot)
+{
+    c->has_depth[slot] = 1;  // a peer's finished map (semidense_flag_, PM.cc:294)
+    // whole map: this rank did not reconstruct it (no claim about its support); compact: values at this keyframe's list
+    // pixels, zero elsewhere -- a pipeline map like the sender's
+    c->recon_lambdaG[slot] = c->xchg_entries > 0 ? c->dprm.lambdaG : std::nanf("");
+}
+// floats2 per map on the wire and in the staging / landing buffers
+long long xchg_stride(const sdm_ctx* c) { return c->xchg_entries > 0 ? (long long)c->xchg_entries + XCHG_HEADER : c->P; }
+
+// staging (outgoing) and landing (incoming) buffers of at least this many maps of the current wire format
+int ensure_xchg_buffers(sdm_ctx* c, long long stage_maps, long long gather_maps)
+{
+    const long long M = xchg_stride(c);
+    if (c->stage_slots < stage_maps) {
+        if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+        (void)hipFree(c->stage_buf);
+        c->stage_buf = nullptr;
+        c->stage_slots = 0;
+        HIP_TRY(hipMalloc((void**)&c->stage_buf, sizeof(float2) * (size_t)M * (size_t)stage_maps));
+        c->stage_slots = (int)stage_maps;
+    }
+    if (c->gather_slots < gather_maps) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // earlier fetch copies may still read the old buffer
+        if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+        (void)hipFree(c->gather_buf);
+        c->gather_buf = nullptr;
+        c->gather_slots = 0;
+        HIP_TRY(hipMalloc((void**)&c->gather_buf, sizeof(float2) * (size_t)M * (size_t)gather_maps));
+        c->gather_slots = gather_maps;
     }
     return SDM_OK;
 }
@@ -271,9 +412,21 @@ int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const 
     for (int i = 0; i < n_send; i++)
         if (!c->has_depth[send_slot[i]]) return fail(SDM_ESTATE, "send slot has no reconstructed depth map");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    const bool compact = c->xchg_entries > 0;
+    const long long M = xchg_stride(c);
+    if (compact) {
+        if ((rc = check_compact_sources(c, n_send, send_slot))) return rc;
+        if ((rc = ensure_xchg_buffers(c, n_send, n_recv))) return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
-    const size_t count = (size_t)c->P * 2;  // floats per map {rho,sigma}
+    if (compact) {
+        if ((rc = prepare_compact_destinations(c, n_recv, recv_slot, c->comm_stream))) return rc;
+        std::vector<float2*> bufs((size_t)n_send);
+        for (int i = 0; i < n_send; i++) bufs[i] = c->stage_buf + (long long)i * M;
+        if ((rc = list_kernel(c, true, n_send, send_slot, bufs.data(), c->comm_stream))) return rc;
+    }
+    const size_t count = (size_t)M * 2;  // floats per map {rho,sigma} on the wire
     ncclComm_t comm = (ncclComm_t)c->comm;
     // one group: all sends and receives of this rank progress together (no ordering deadlock between peers).  A
     // failing call must not leave the thread's group open (every later RCCL call of the thread, torch's included,
@@ -282,21 +435,25 @@ int sdm_exchange_halo_begin(sdm_ctx* c, int n_send, const int* send_peer, const 
     ncclResult_t first = ncclSuccess;
     const char* what = "";
     for (int i = 0; i < n_send && first == ncclSuccess; i++) {
-        first = g_rccl.Send(c->pool + (long long)send_slot[i] * c->P, count, ncclFloat, send_peer[i], comm, c->comm_stream);
+        const float2* src = compact ? c->stage_buf + (long long)i * M : c->pool + (long long)send_slot[i] * c->P;
+        first = g_rccl.Send(src, count, ncclFloat, send_peer[i], comm, c->comm_stream);
         what = "ncclSend";
     }
     for (int i = 0; i < n_recv && first == ncclSuccess; i++) {
-        first = g_rccl.Recv(c->pool + (long long)recv_slot[i] * c->P, count, ncclFloat, recv_peer[i], comm, c->comm_stream);
+        float2* dst = compact ? c->gather_buf + (long long)i * M : c->pool + (long long)recv_slot[i] * c->P;
+        first = g_rccl.Recv(dst, count, ncclFloat, recv_peer[i], comm, c->comm_stream);
         what = "ncclRecv";
     }
     const ncclResult_t ended = g_rccl.GroupEnd();
     if (first != ncclSuccess) return fail(SDM_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(first));
     if (ended != ncclSuccess) return fail(SDM_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ended));
-    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
-    for (int i = 0; i < n_recv; i++) {
-        c->has_depth[recv_slot[i]] = 1;                    // a peer's finished map (semidense_flag_, PM.cc:294)
-        c->recon_lambdaG[recv_slot[i]] = std::nanf("");    // this rank did not reconstruct it
+    if (compact) {
+        std::vector<float2*> bufs((size_t)n_recv);
+        for (int i = 0; i < n_recv; i++) bufs[i] = c->gather_buf + (long long)i * M;
+        if ((rc = list_kernel(c, false, n_recv, recv_slot, bufs.data(), c->comm_stream))) return rc;
     }
+    HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
+    for (int i = 0; i < n_recv; i++) mark_received(c, recv_slot[i]);
     c->xchg_pending = true;
     return SDM_OK;
 }
@@ -333,6 +490,8 @@ int sdm_allgather_depth(sdm_ctx* c, int first_slot, int count, int n_fetch, cons
     if (count < 1 || first_slot < 0 || first_slot + count > c->cfg.max_keyframes)
         return fail(SDM_EINVAL, "block out of range");
     if (n_fetch > 0 && (!fetch_index || !dst_slot)) return fail(SDM_EINVAL, "null fetch list");
+    if (c->xchg_entries > 0)
+        return fail(SDM_ESTATE, "the one-shot all-gather moves whole maps: sdm_exchange_compact(ctx, 0) first, or use the pieces");
     const long long total = (long long)c->world * count;
     for (int i = 0; i < n_fetch; i++) {
         if (fetch_index[i] < 0 || fetch_index[i] >= total) return fail(SDM_EINVAL, "fetch index out of range");
@@ -413,15 +572,7 @@ int sdm_allgather_begin(sdm_ctx* c, int maps_per_rank)
     int rc = comm_streams(c);
     if (rc) return rc;
     const long long total = (long long)c->world * maps_per_rank;
-    if (c->gather_slots < total) {
-        HIP_TRY(hipStreamSynchronize(c->stream));  // earlier fetch copies may still read the old buffer
-        HIP_TRY(hipStreamSynchronize(c->comm_stream));
-        (void)hipFree(c->gather_buf);
-        c->gather_buf = nullptr;
-        c->gather_slots = 0;
-        HIP_TRY(hipMalloc((void**)&c->gather_buf, sizeof(float2) * (size_t)c->P * (size_t)total));
-        c->gather_slots = total;
-    }
+    if ((rc = ensure_xchg_buffers(c, 0, total))) return rc;
     // the previous pass's fetch copies (compute stream) must have left the buffer before new pieces land in it
     HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
@@ -446,31 +597,32 @@ int sdm_allgather_piece(sdm_ctx* c, int count, const int* slots)
         contiguous = contiguous && slots[i] == slots[0] + i;
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc;
+    const bool compact = c->xchg_entries > 0;
+    const long long M = xchg_stride(c);
+    if (compact && (rc = check_compact_sources(c, count, slots))) return rc;
+    if ((compact || !contiguous) && (rc = ensure_xchg_buffers(c, c->ag_count, 0))) return rc;
     HIP_TRY(hipEventRecord(c->ev_maps_ready, c->stream));  // this piece's K1-K3 are queued on the compute stream
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_maps_ready, 0));
     const int offset = c->ag_covered;
     const float2* src = c->pool + (long long)slots[0] * c->P;
-    if (!contiguous) {
-        if (c->stage_slots < c->ag_count) {
-            HIP_TRY(hipStreamSynchronize(c->comm_stream));
-            (void)hipFree(c->stage_buf);
-            c->stage_buf = nullptr;
-            c->stage_slots = 0;
-            HIP_TRY(hipMalloc((void**)&c->stage_buf, sizeof(float2) * (size_t)c->P * (size_t)c->ag_count));
-            c->stage_slots = c->ag_count;
-        }
+    if (compact) {  // the listed pixels of every map of the piece, in list order
+        std::vector<float2*> bufs((size_t)count);
+        for (int i = 0; i < count; i++) bufs[i] = c->stage_buf + (long long)(offset + i) * M;
+        if ((rc = list_kernel(c, true, count, slots, bufs.data(), c->comm_stream))) return rc;
+        src = c->stage_buf + (long long)offset * M;
+    } else if (!contiguous) {
         std::vector<const float2*> srcs((size_t)count);
         std::vector<float2*> dsts((size_t)count);
         for (int i = 0; i < count; i++) {
             srcs[i] = c->pool + (long long)slots[i] * c->P;
             dsts[i] = c->stage_buf + (long long)(offset + i) * c->P;
         }
-        int rc = copy_maps(c, count, srcs.data(), dsts.data(), c->comm_stream);
-        if (rc) return rc;
+        if ((rc = copy_maps(c, count, srcs.data(), dsts.data(), c->comm_stream))) return rc;
         src = c->stage_buf + (long long)offset * c->P;
     }
-    const size_t piece_floats = (size_t)count * (size_t)c->P * 2;
-    float2* dst = c->gather_buf + (long long)c->world * offset * c->P;  // pieces before this one hold world*offset maps
+    const size_t piece_floats = (size_t)count * (size_t)M * 2;
+    float2* dst = c->gather_buf + (long long)c->world * offset * M;  // pieces before this one hold world*offset maps
     if (!c->comm) {
         HIP_TRY(hipMemcpyAsync(dst, src, piece_floats * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
     } else {
@@ -501,6 +653,8 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
     // the fetch copies run on the EXCHANGE stream behind the last piece; the compute stream only waits for them.  What
     // the caller queued on the compute stream before this call (the interior keyframes' K1-K3 and K4) neither reads nor
     // writes the destination slots' maps, so the copies overlap it.
+    const bool compact = c->xchg_entries > 0;
+    const long long M = xchg_stride(c);
     std::vector<const float2*> srcs((size_t)n_fetch);
     std::vector<float2*> dsts((size_t)n_fetch);
     for (int i = 0; i < n_fetch; i++) {
@@ -508,19 +662,71 @@ int sdm_allgather_finish(sdm_ctx* c, int n_fetch, const int* fetch_index, const 
         const float2* src = nullptr;
         for (const auto& pc : c->ag_pieces)
             if (pos >= pc.offset && pos < pc.offset + pc.count)
-                src = c->gather_buf + ((long long)c->world * pc.offset + (long long)owner * pc.count + (pos - pc.offset)) * c->P;
+                src = c->gather_buf + ((long long)c->world * pc.offset + (long long)owner * pc.count + (pos - pc.offset)) * M;
         srcs[i] = src;
         dsts[i] = c->pool + (long long)dst_slot[i] * c->P;
     }
-    int rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->comm_stream);
-    if (rc) return rc;
+    int rc;
+    if (compact) {
+        if ((rc = prepare_compact_destinations(c, n_fetch, dst_slot, c->comm_stream))) return rc;
+        std::vector<float2*> bufs((size_t)n_fetch);
+        for (int i = 0; i < n_fetch; i++) bufs[i] = const_cast<float2*>(srcs[i]);
+        if ((rc = list_kernel(c, false, n_fetch, dst_slot, bufs.data(), c->comm_stream))) return rc;
+    } else if ((rc = copy_maps(c, n_fetch, srcs.data(), dsts.data(), c->comm_stream))) {
+        return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev_xchg_done, c->comm_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xchg_done, 0));
-    for (int i = 0; i < n_fetch; i++) {
-        c->has_depth[dst_slot[i]] = 1;
-        c->recon_lambdaG[dst_slot[i]] = std::nanf("");
-    }
+    for (int i = 0; i < n_fetch; i++) mark_received(c, dst_slot[i]);
     c->ag_open = false;
+    return SDM_OK;
+}
+
+// Wire format of the maps that cross ranks (halo and all-gather-in-pieces forms; the one-shot sdm_allgather_depth always
+// moves whole maps).  entries_per_map = 0: whole maps, 8P bytes each.  > 0: the {rho,sigma} of the first entries_per_map
+// entries of the keyframe's active-pixel list, in list order -- everything a reconstructed map holds (it is zero outside
+// the list), 8 * entries_per_map bytes.  Every rank must set the SAME value, no shorter than the longest list among the
+// keyframes it sends or receives (sdm_active_count; the call that would send or receive a longer one fails with
+// SDM_ESTATE before anything is posted -- agree on the value across ranks first, as bench.py does).  The receiver must
+// hold the keyframe (its image, hence its list) in the destination slot: true for the input halo of a sharded sequence.
+int sdm_exchange_compact(sdm_ctx* c, int entries_per_map)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (entries_per_map < 0 || entries_per_map > c->P) return fail(SDM_EINVAL, "entries_per_map out of range");
+    if (c->xchg_pending || c->ag_open) return fail(SDM_ESTATE, "an exchange is in flight");
+    if (entries_per_map == c->xchg_entries) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    (void)hipFree(c->gather_buf);  // sized in maps of the old format
+    c->gather_buf = nullptr;
+    c->gather_slots = 0;
+    (void)hipFree(c->stage_buf);
+    c->stage_buf = nullptr;
+    c->stage_slots = 0;
+    if (entries_per_map > 0 && !c->d_xchg_mismatch) {
+        HIP_TRY(hipMalloc((void**)&c->d_xchg_mismatch, sizeof(unsigned)));
+        HIP_TRY(hipMemset(c->d_xchg_mismatch, 0, sizeof(unsigned)));
+    }
+    c->xchg_entries = entries_per_map;
+    return SDM_OK;
+}
+
+// Compact maps whose sender's list length differed from the receiver's (they were NOT scattered; the destination plane
+// keeps what it held): the count since the last call, after waiting for everything queued.  0 on a healthy job -- the lists
+// are a function of the keyframe's image and lambdaG, which sender and receiver share.
+int sdm_exchange_mismatches(sdm_ctx* c, int* count)
+{
+    if (!c || !count) return fail(SDM_EINVAL, "null argument");
+    *count = 0;
+    if (!c->d_xchg_mismatch) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    unsigned v = 0;
+    HIP_TRY(hipMemcpy(&v, c->d_xchg_mismatch, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->d_xchg_mismatch, 0, sizeof(unsigned)));
+    *count = (int)v;
     return SDM_OK;
 }
 

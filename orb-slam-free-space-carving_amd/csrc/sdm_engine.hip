@@ -176,6 +176,8 @@ struct sdm_ctx {
     float2* stage_buf = nullptr;        // packing buffer for pieces that are not runs of consecutive slots
     int stage_slots = 0;
     int* d_agree = nullptr;  // sdm_comm_all_ok
+    int xchg_entries = 0;    // sdm_exchange_compact: > 0 = maps cross ranks as their first xchg_entries active-list entries
+    unsigned* d_xchg_mismatch = nullptr;  // compact maps refused by k_unpack_lists (list lengths differ)
 };
 
 namespace {
@@ -952,6 +954,19 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
         hipLaunchKernelGGL(k_fuse_open<false>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
                            c->P * c->cfg.max_keyframes, c->d_stats);
     HIP_TRY(hipGetLastError());
+    return SDM_OK;
+}
+
+int sdm_active_count(sdm_ctx* c, int slot, int* count)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!count) return fail(SDM_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!(c->act_lambdaG[slot] == c->dprm.lambdaG))
+        if ((rc = build_active(c, slot))) return rc;
+    if ((rc = sync_counts(c))) return rc;
+    *count = c->h_act_count[slot];
     return SDM_OK;
 }
 

@@ -249,6 +249,24 @@ def setup_native_comm(eng, group=None):
     eng.comm_init(box[0], world, rank)
 
 
+def agree_compact_wire(eng, pl, group=None, max_fraction=0.5):
+    """Chooses the wire format of the native exchange for this job (every rank calls this; one all-reduce): the maps that
+    cross ranks travel as the {rho,sigma} of their keyframe's active-list entries (sdm_exchange_compact) if the longest
+    list among ALL ranks' keyframes, rounded up to 64 entries, is at most `max_fraction` of the pixels -- else whole maps.
+    Returns the entries per map (0 = whole maps)."""
+    longest = max([eng.active_count(s) for s in range(pl["n_slots"])] + [0])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([longest], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        longest = int(t.item())
+    entries = (longest + 63) // 64 * 64
+    if entries == 0 or entries > max_fraction * eng.W * eng.H:
+        entries = 0
+    eng.exchange_compact(entries)
+    return entries
+
+
 _gather_cache = {}
 
 

@@ -172,12 +172,111 @@ def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
     eng.inter_check(pl["own_slots"], pl["nbr_slots"])
     want = [eng.download_checked(k) for k in refs]
     assert float(np.abs(want[4]).sum()) > 0
-    for exch, pieces in (("halo", 1), ("allgather", 1), ("allgather_full", 3)):
-        pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native",
-                                ag_pieces=pieces, force_pieces=True)
-        for k in refs:
-            assert_bit_equal(eng.download_checked(k), want[k], "checked rho kf %d (%s over RCCL)" % (k, exch))
+    for wire in ("whole", "compact"):
+        entries = pkg.shard.agree_compact_wire(eng, pl) if wire == "compact" else 0
+        assert (entries > 0) == (wire == "compact")
+        for exch, pieces in (("halo", 1), ("allgather", 1), ("allgather_full", 3)):
+            pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native",
+                                    ag_pieces=pieces, force_pieces=True)
+            for k in refs:
+                assert_bit_equal(eng.download_checked(k), want[k], "checked rho kf %d (%s over RCCL, %s)" % (k, exch, wire))
+    eng.exchange_compact(0)
     eng.comm_destroy()
+    eng.close()
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_compact_wire_format(pkg, oracle, gpu_ok, monkeypatch, rccl):
+    """sdm_exchange_compact: maps cross ranks as the {rho,sigma} of their keyframe's active-list entries and are scattered
+    through the RECEIVER's list of the same keyframe (its input halo holds the image).  One GPU: keyframe k is resident
+    twice (slots k and 8+k, as on two ranks); every map that went through pack -> gather -> unpack (device-copy stand-in,
+    or a real one-rank RCCL communicator: all-gather pieces and grouped send/recv) equals its source bit for bit -- also
+    into a destination plane that held an arbitrary map before."""
+    if rccl:
+        monkeypatch.setenv("SDM_COMM_SINGLE_RANK_RCCL", "1")
+    seq = Sequence(pkg, oracle, 96, 72, 8, 0x5EED0C14)
+    n, K = 5, seq.n_kf
+    eng = pkg.Engine(seq.W, seq.H, 2 * K, max_neighbours=n)
+    seq.upload(eng, device_prepass=True)
+    for k in range(K):  # the same keyframes again, as another rank's input halo would hold them
+        eng.upload_image(K + k, seq.im[k], seq.K, seq.Tcw[k])
+    if rccl:
+        try:
+            eng.comm_init(eng.comm_unique_id(), 1, 0)
+        except pkg.SdmError as e:
+            eng.close()
+            if e.code != 5:
+                raise
+            pytest.skip("RCCL communicator cannot be created here: %s" % e)
+    refs = list(range(K))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    maps = {k: eng.download_depth(k) for k in refs}
+    counts = [eng.active_count(k) for k in range(2 * K)]
+    assert counts[:K] == counts[K:] and max(counts) > 100
+    E = (max(counts) + 63) // 64 * 64
+    assert E < seq.W * seq.H // 2
+    with pytest.raises(pkg.SdmError) as e:
+        eng.exchange_compact(seq.W * seq.H + 1)
+    assert e.value.code == 1
+    eng.exchange_compact(min(counts) - 1)  # too short for at least one list
+    eng.allgather_begin(K)
+    with pytest.raises(pkg.SdmError) as e:
+        eng.allgather_piece(refs)
+    assert e.value.code == 4
+    eng.close()
+
+    eng = pkg.Engine(seq.W, seq.H, 2 * K, max_neighbours=n)
+    seq.upload(eng, device_prepass=True)
+    for k in range(K):
+        eng.upload_image(K + k, seq.im[k], seq.K, seq.Tcw[k])
+    if rccl:
+        eng.comm_init(eng.comm_unique_id(), 1, 0)
+    eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+    eng.exchange_compact(E)
+    with pytest.raises(pkg.SdmError) as e:  # the one-shot form moves whole maps only
+        eng.allgather_depth(0, K, fetch=[])
+    assert e.value.code == 4
+    rng = np.random.default_rng(5)
+    junk = rng.random((seq.H, seq.W), dtype=np.float32)
+    eng.upload_depth(K + 3, junk, junk)  # an arbitrary map in a destination plane: zeroed before the scatter
+    order = [[0, 1, 2], [5, 3, 4], [7, 6]]
+    flat = [k for piece in order for k in piece]
+    eng.allgather_begin(K)
+    for piece in order:
+        eng.allgather_piece(piece)
+    eng.allgather_finish([(pos, K + flat[pos]) for pos in range(K)])
+    for k in refs:
+        r, sg = eng.download_depth(K + k)
+        assert_bit_equal(r, maps[k][0], "compact all-gather rho kf %d" % k)
+        assert_bit_equal(sg, maps[k][1], "compact all-gather sigma kf %d" % k)
+    assert float(np.abs(maps[5][0]).sum()) > 0
+    assert eng.exchange_mismatches() == 0
+    # K4 reads the received copies like the originals
+    eng.inter_check([4], [nbrs[4]])
+    want = eng.download_checked(4)
+    eng.inter_check([4], [[K + j for j in nbrs[4]]])
+    assert_bit_equal(eng.download_checked(4), want, "K4 against compact-received maps")
+    if rccl:  # grouped send / recv in compact form (to itself), into planes that hold the previous maps
+        eng.recon([1, 6], [nbrs[1], nbrs[6]], seq.min_depth, seq.max_depth)
+        eng.exchange_halo([(0, 1), (0, 6)], [(0, K + 1), (0, K + 6)])
+        for k in (1, 6):
+            r, sg = eng.download_depth(K + k)
+            assert_bit_equal(r, maps[k][0], "compact send/recv rho kf %d" % k)
+            assert_bit_equal(sg, maps[k][1])
+        eng.comm_destroy()  # also back to whole maps: the wire format belongs to the communicator's agreement
+        eng.exchange_compact(E)
+    # a receiver whose image of the keyframe differs from the sender's (another list) refuses the map and says so
+    eng.upload_image(K + 2, seq.im[5], seq.K, seq.Tcw[5])
+    assert eng.active_count(K + 2) != eng.active_count(2)
+    before = eng.download_depth(K + 2)
+    eng.allgather_begin(1)
+    eng.allgather_piece([2])
+    eng.allgather_finish([(0, K + 2)])
+    assert eng.exchange_mismatches() == 1 and eng.exchange_mismatches() == 0
+    assert_bit_equal(eng.download_depth(K + 2)[0], before[0], "a refused map leaves the destination untouched")
+    eng.exchange_compact(0)
+    eng.allgather_depth(0, K, fetch=[])  # whole maps again
     eng.close()
 
 
