@@ -128,6 +128,7 @@ struct Options {
     int max_keyframes = 64;          /* device slots; least-recently-used keyframes are evicted */
     std::string obj_path = "semi_pointcloud.obj"; /* written when Run() ends, PM.cc:100 */
     unsigned poll_us = 5000;         /* Run()'s usleep, PM.cc:87 */
+    bool exchange_compact = true;    /* sharded passes: maps cross ranks as their active-list entries (sdm_exchange_compact) */
 };
 
 }  // namespace sdm

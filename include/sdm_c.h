@@ -227,6 +227,9 @@ int sdm_active_count(sdm_ctx *ctx, int slot, int *count);
  * A rank that cannot take part in the exchange it planned reports it here, so peers skip the pass instead of
  * waiting for transfers that never come. */
 int sdm_comm_all_ok(sdm_ctx *ctx, int local_ok, int *all_ok);
+/* *all_max = max over ranks of local_value (all ranks call it; host-blocking; world size 1: the local value) -- e.g. the
+ * longest active list of the job, for sdm_exchange_compact. */
+int sdm_comm_all_max(sdm_ctx *ctx, int local_value, int *all_max);
 
 /* ---- stand-alone map operations with the reference's signatures -------------------------------- */
 /* IntraKeyFrameDepthChecking(cv::Mat&, cv::Mat&, const cv::Mat) PM.h:85; host maps, in place. */

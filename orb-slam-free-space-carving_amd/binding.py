@@ -86,6 +86,7 @@ SYMBOLS = [
     ("sdm_allgather_piece", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_allgather_finish", C.c_int, [_ctx, C.c_int, _ip, _ip]),
     ("sdm_comm_all_ok", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_comm_all_max", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_exchange_compact", C.c_int, [_ctx, C.c_int]),
     ("sdm_exchange_mismatches", C.c_int, [_ctx, _ip]),
     ("sdm_active_count", C.c_int, [_ctx, C.c_int, _ip]),
@@ -395,6 +396,11 @@ class Engine:
         fi, fip = _i32([i for i, _ in fetch])
         ds, dsp = _i32([s for _, s in fetch])
         self._check(self.lib.sdm_allgather_finish(self.ctx, len(fetch), fip, dsp))
+
+    def comm_all_max(self, value):
+        out = C.c_int()
+        self._check(self.lib.sdm_comm_all_max(self.ctx, int(value), C.byref(out)))
+        return int(out.value)
 
     def exchange_compact(self, entries_per_map):
         """0 = whole maps cross ranks; > 0 = the {rho,sigma} of the first entries_per_map active-list entries"""

@@ -750,6 +750,22 @@ int sdm_comm_all_ok(sdm_ctx* c, int local_ok, int* all_ok)
     return SDM_OK;
 }
 
+int sdm_comm_all_max(sdm_ctx* c, int local_value, int* all_max)
+{
+    if (!c || !all_max) return fail(SDM_EINVAL, "null argument");
+    *all_max = local_value;
+    if (!c->comm) return SDM_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->d_agree) HIP_TRY(hipMalloc((void**)&c->d_agree, sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(c->d_agree, &local_value, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(g_rccl.AllReduce(c->d_agree, c->d_agree, 1, ncclInt, ncclMax, (ncclComm_t)c->comm, c->stream));
+    int out = 0;
+    HIP_TRY(hipMemcpyAsync(&out, c->d_agree, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *all_max = out;
+    return SDM_OK;
+}
+
 // Maps written into the depth pool from outside the engine (an ext_depth_pool filled by the host framework's
 // own collective): marks the slots as holding finished depth maps (kf->semidense_flag_, PM.cc:292-298).
 int sdm_mark_depth_present(sdm_ctx* c, int n, const int* slots)

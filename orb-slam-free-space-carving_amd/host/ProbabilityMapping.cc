@@ -646,6 +646,27 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         if (local_ok) std::cerr << "ProbabilityMapping::SemiDenseReconBlock: another rank cannot run this pass; skipped" << std::endl;
         return;
     }
+    if (world > 1) {
+        // wire format of this pass: the longest active list among the keyframes ANY rank touches, rounded up to 64 entries
+        // (the same on every rank by construction: one all-reduce); whole maps if that is more than half a plane
+        int longest = 0, all_longest = 0, entries = 0;
+        for (int i = 0; i < n_all && opt_.exchange_compact; i++) {
+            int cnt = 0;
+            if (needed[i] && sdm_active_count(ctx_, slot[i], &cnt) == SDM_OK) longest = std::max(longest, cnt);
+        }
+        if (sdm_comm_all_max(ctx_, longest, &all_longest) != SDM_OK) {
+            report("SemiDenseReconBlock");
+            return;
+        }
+        if (opt_.exchange_compact) {
+            entries = (all_longest + 63) / 64 * 64;
+            if (entries * 2 > all[first]->im_.cols * all[first]->im_.rows) entries = 0;
+        }
+        if (sdm_exchange_compact(ctx_, entries) != SDM_OK) {
+            report("SemiDenseReconBlock");
+            return;
+        }
+    }
 
     std::vector<int> send_peer = plan.send_peer, recv_peer = plan.recv_peer, send_slot, recv_slot;
     for (int j : plan.send_kf) send_slot.push_back(slot[j]);

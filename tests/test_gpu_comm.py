@@ -102,6 +102,7 @@ def test_allgather_pieces_addressing(pkg, oracle, gpu_ok):
         assert_bit_equal(sg, maps[flat[pos]][1], "fetched sigma at position %d" % pos)
     assert float(np.abs(maps[5][0]).sum()) > 0
     assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # world size 1: the local verdict
+    assert eng.comm_all_max(77) == 77
     eng.close()
 
 
@@ -124,6 +125,7 @@ def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
         pytest.skip("RCCL communicator cannot be created here: %s" % e)
     assert eng.comm_info() == (1, 0)
     assert eng.comm_all_ok(True) is True and eng.comm_all_ok(False) is False  # ncclAllReduce(min)
+    assert eng.comm_all_max(12345) == 12345 and eng.comm_all_max(0) == 0        # ncclAllReduce(max)
     refs = list(range(seq.n_kf))
     nbrs = [seq.neighbours(k, n) for k in refs]
     # pieces gathered while the next keyframes are reconstructed
