@@ -422,6 +422,7 @@ def main():
             rccl_world = eng.comm_info()[0]
         else:
             transport = "torch"
+            wire_entries = 0  # the torch transport exchanges whole maps
             transport_note = "native RCCL exchange failed on at least one rank (%s): fell back to torch.distributed" % (
                 why or "another rank")
             try:
