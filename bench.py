@@ -57,11 +57,12 @@ def parse():
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
-    ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather", "allgather_full"],
+    ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather", "allgather_late", "allgather_full"],
                     help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: "
                          "allgather = RCCL all-gather of the maps that cross ranks (every rank's boundary keyframes, "
                          "overlapped with the reconstruction of the interior ones); allgather_full = every rank's whole "
-                         "block, pipelined in sub-blocks (BASELINE.json's literal wording, 3x the bytes); halo = "
+                         "block, pipelined in sub-blocks (BASELINE.json's literal wording, 3x the bytes); allgather_late = the boundary "
+                         "all-gather after an UNSPLIT reconstruction, hidden behind the local keyframes' K4 only; halo = "
                          "point-to-point.  The other forms are timed too: exchange_ms_per_step, value_<form>")
     ap.add_argument("--wire", default="compact", choices=["compact", "whole"],
                     help="native transport: what crosses ranks per depth map -- the {rho,sigma} of the keyframe's active-list "
@@ -456,7 +457,7 @@ def main():
     exchange_ms, others = None, {}
     if exchanging:  # the other exchange forms, same K steps, so the line carries all three
         exchange_ms = {args.exchange: round(dt / args.steps * 1e3, 4)}
-        for other in ("allgather", "allgather_full", "halo"):
+        for other in ("allgather", "allgather_late", "allgather_full", "halo"):
             if other == args.exchange:
                 continue
             dt2, _ = timed(wl, args.steps, min(args.warmup, 2), barrier, other, transport)
@@ -527,7 +528,8 @@ def main():
             out["value_" + other] = round(P * n_total * args.steps / dt2 / 1e6, 2)
         out["config"]["allgather_full_pieces"] = pkg.shard.AG_PIECES if transport == "native" else 1
         out["config"]["exchange_maps_per_rank"] = {  # maps every rank RECEIVES per step
-            "allgather": (world - 1) * pl["contrib_count"], "allgather_full": (world - 1) * pl["count"],
+            "allgather": (world - 1) * pl["contrib_count"], "allgather_late": (world - 1) * pl["contrib_count"],
+            "allgather_full": (world - 1) * pl["count"],
             "halo": sum(len(v) for v in pl["recv"].values())}
         out["config"]["exchange_wire"] = (
             {"format": "{rho,sigma} of the keyframe's active-list entries (sdm_exchange_compact); the receiver scatters them "

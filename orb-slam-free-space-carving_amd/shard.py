@@ -291,8 +291,9 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
     multi-rank tests check): SemiDenseRecon (K1-K3) -> exchange of {rho,sigma} maps -> inter-keyframe
     check (K4, snapshot form) + point set (K5; back-projected in the checking kernel).
 
-    exchange: "allgather" (boundary keyframes, overlapped), "allgather_full" (whole block, pipelined in sub-blocks) or
-    "halo" (point-to-point); see the module docstring.  force_pieces: run the all-gather bookkeeping at world size 1
+    exchange: "allgather" (boundary keyframes, overlapped with the interior keyframes' K1-K3 and K4), "allgather_late" (the
+    same collective after an unsplit reconstruction, overlapped with the local K4 only), "allgather_full" (whole block,
+    pipelined in sub-blocks) or "halo" (point-to-point); see the module docstring.  force_pieces: run the all-gather bookkeeping at world size 1
     (the tests' rehearsal)."""
     world = pl["world"]
     own, nbrs = pl["own_slots"], pl["nbr_slots"]
@@ -341,6 +342,21 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
             allgather_boundary(pool, pl, group)
             if rest:
                 eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            check(early)
+            eng.mark_depth_present([s for _, s in contrib_fetch_list(pl)])
+        check(late)
+    elif exchange == "allgather_late" and (world > 1 or force_pieces):
+        # the boundary all-gather WITHOUT splitting the reconstruction: K1-K3 over the whole block in one set of launches (no
+        # second K1 launch with its tail), then the collective with only the local keyframes' K4 to hide behind.  Cheaper on
+        # the compute side, a third of the window: the better schedule when the transfer is short (compact wire format).
+        eng.recon(own, nbrs, min_d, max_d)
+        if native:
+            eng.allgather_begin(pl["contrib_count"])
+            eng.allgather_piece(contrib_slots(pl))
+            check(early)
+            eng.allgather_finish(contrib_fetch_list(pl))
+        else:
+            allgather_boundary(pool, pl, group)
             check(early)
             eng.mark_depth_present([s for _, s in contrib_fetch_list(pl)])
         check(late)

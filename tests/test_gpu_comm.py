@@ -177,7 +177,7 @@ def test_rccl_single_rank_rehearsal(pkg, oracle, gpu_ok, monkeypatch):
     for wire in ("whole", "compact"):
         entries = pkg.shard.agree_compact_wire(eng, pl) if wire == "compact" else 0
         assert (entries > 0) == (wire == "compact")
-        for exch, pieces in (("halo", 1), ("allgather", 1), ("allgather_full", 3)):
+        for exch, pieces in (("halo", 1), ("allgather", 1), ("allgather_late", 1), ("allgather_full", 3)):
             pkg.shard.pipeline_step(eng, None, pl, seq.min_depth, seq.max_depth, exch, transport="native",
                                     ag_pieces=pieces, force_pieces=True)
             for k in refs:

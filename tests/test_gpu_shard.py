@@ -47,7 +47,7 @@ def _single_rank(pkg, n_total, n_nbr):
     return res
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (2, "allgather_full"), (3, "halo"), (3, "allgather")])
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (2, "allgather_full"), (3, "halo"), (3, "allgather"), (2, "allgather_late")])
 def test_sharded_equals_single_rank(pkg, gpu_ok, tmp_path, world, exchange):
     n_total, n_nbr = 12, 4
     want = _single_rank(pkg, n_total, n_nbr)
