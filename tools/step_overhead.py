@@ -34,7 +34,7 @@ eng, pl = wl.eng, wl.pl
 own, nbrs = pl["own_slots"], pl["nbr_slots"]
 nb_of = dict(zip(own, nbrs))
 boundary, interior = pl["boundary_slots"], pl["interior_slots"]
-early, late = pl["check_early_slots"], pl["check_late_slots"]
+early, late_slots = pl["check_early_slots"], pl["check_late_slots"]
 contrib = shard.contrib_slots(pl)
 cc = pl["contrib_count"]
 fake_fetch = [(i % cc, s) for i, (_, s) in enumerate(shard.contrib_fetch_list(pl))]
@@ -54,7 +54,16 @@ def split():
     eng.recon(interior, [nb_of[k] for k in interior], wl.min_d, wl.max_d)
     eng.inter_check_pointset(early, [nb_of[k] for k in early], commit=False)
     eng.allgather_finish(fake_fetch)
-    eng.inter_check_pointset(late, [nb_of[k] for k in late], commit=False)
+    eng.inter_check_pointset(late_slots, [nb_of[k] for k in late_slots], commit=False)
+
+
+def late():  # the boundary all-gather after an UNSPLIT reconstruction (exchange="allgather_late")
+    eng.recon(own, nbrs, wl.min_d, wl.max_d)
+    eng.allgather_begin(cc)
+    eng.allgather_piece(contrib)
+    eng.inter_check_pointset(early, [nb_of[k] for k in early], commit=False)
+    eng.allgather_finish(fake_fetch)
+    eng.inter_check_pointset(late_slots, [nb_of[k] for k in late_slots], commit=False)
 
 
 split()  # fills the halo slots
@@ -63,9 +72,9 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.5:
     plain()
 torch.cuda.synchronize()
-res = {"plain": [], "split": []}
+res = {"plain": [], "split": [], "late": []}
 for _ in range(a.rounds):
-    for name, fn in (("plain", plain), ("split", split)):
+    for name, fn in (("plain", plain), ("split", split), ("late", late)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -75,7 +84,7 @@ for _ in range(a.rounds):
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
 eng.enable_timing(True)
-for name, fn in (("plain", plain), ("split", split)):
+for name, fn in (("plain", plain), ("split", split), ("late", late)):
     eng.get_timing(reset=True)
     for _ in range(a.steps):
         fn()
@@ -88,5 +97,6 @@ for name in res:
     v = sorted(res[name])
     print("%s %s: median %.4f ms per step (min %.4f, max %.4f)" % (a.res, name, v[len(v) // 2], v[0], v[-1]))
 p, s = sorted(res["plain"])[a.rounds // 2], sorted(res["split"])[a.rounds // 2]
-print("compute-side ceiling of the weak-scaling efficiency (transfer fully hidden): %.3f" % (p / s))
+print("compute-side ceiling of the weak-scaling efficiency (transfer fully hidden): %.3f split, %.3f late" % (
+    p / s, p / sorted(res["late"])[a.rounds // 2]))
 wl.close()
