@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="N>1: RCCL called by the engine's C ABI (sdm_exchange_*) or torch.distributed on the pool tensor")
     ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (SURVEY.md §8d adversarial set)")
+    ap.add_argument("--outliers", type=int, default=0,
+                    help="N=1: this many of every keyframe's neighbours are wrong-pose copies (K1 only is stepped: the "
+                         "profiling form of the extra_configs outlier line)")
     ap.add_argument("--independent", action="store_true",
                     help="N>1: one independent sequence per GPU, no exchange (BASELINE.json configs[4])")
     return ap.parse_args()
@@ -271,7 +274,7 @@ def measure(wl, steps, warmup, barrier, exchange, transport, reduce_max=None):
     return dt, timing, dt_c, timing_c, n_pre
 
 
-def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps):
+def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False, outliers=0):
     """HBM-side bytes of one k_search_fuse launch from a committed PMC run (tools/pmc.sh: rocprofv3 cannot
     run inside bench.py).  Only a file whose workload AND kernel-source hash match this build is used."""
     src = source_hash()
@@ -287,7 +290,8 @@ def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps):
             continue
         w = t.get("workload", {})
         if t.get("src_hash") == src and \
-                (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity")) == (res, kfs, nbrs, disparity):
+                (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity"), bool(w.get("noise", False)),
+                 int(w.get("outliers", 0))) == (res, kfs, nbrs, disparity, bool(noise), int(outliers)):
             return t["traffic_bytes_per_launch"]
     return None
 
@@ -307,8 +311,8 @@ def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, bar
     stats = wl.scan_stats()
     dt, timing, dt_c, timing_c, _ = measure(wl, steps, warmup, barrier, "halo", "torch")
     plain = not (noise or outliers)
-    rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps)
-                          if plain else None)
+    rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps,
+                                                               noise=noise, outliers=outliers))
     rf_c, _ = roofline(wl, timing_c, steps, None)
     rf["frac_cold"] = rf_c["frac"]
     rf["launch_ms_cold"] = rf_c["launch_ms"]
@@ -381,7 +385,7 @@ def main():
         torch.cuda.synchronize()
 
     wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
-                  independent=args.independent, noise=args.noise,
+                  independent=args.independent, noise=args.noise, outliers=(args.outliers if world == 1 else 0),
                   keep_images=(args.cpu_kfs + 2 * args.nbrs) if (rank == 0 and world == 1) else 0)
     eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
     n_total = wl.n_total * (world if args.independent else 1)
@@ -431,17 +435,43 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
 
-    # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as
-    # HOST gray images through sdm_upload_image (H2D copy + device pre-pass + record packing)
-    t_h2d = None
+    # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as HOST gray images
+    # (H2D copy + device pre-pass + record packing + pixel lists): one sdm_upload_images_batch call for the block -- from
+    # ordinary (pageable) arrays through the engine's pinned ring, and from pinned memory (sdm_host_alloc) read in place
+    # -- and, for comparison, one sdm_upload_image call per keyframe
+    upload_ms = None
     if rank == 0 and world == 1 and wl.images:
-        ks = sorted(wl.images)[:16]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in ks:
-            eng.upload_image(pl["slot"][k], wl.images[k], wl.K, wl.scene.Tcw(k))
-        eng.synchronize()
-        t_h2d = (time.perf_counter() - t0) / len(ks)
+        ks = [k for k in pl["own"] if k in wl.images][:64]
+        slots = [pl["slot"][k] for k in ks]
+        ims = [wl.images[k] for k in ks]
+        poses = [wl.scene.Tcw(k) for k in ks]
+        pinned = [eng.host_alloc((H, W)) for _ in ks]
+        for a, im in zip(pinned, ims):
+            a[...] = im
+
+        def timed_upload(fn, reps=3):
+            best = None
+            for _ in range(reps + 1):  # the first pass is a warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                eng.synchronize()
+                dt_ = (time.perf_counter() - t0) / len(ks)
+                best = dt_ if best is None else min(best, dt_)
+            return best
+
+        def single():
+            for s_, im, T in zip(slots, ims, poses):
+                eng.upload_image(s_, im, wl.K, T)
+
+        upload_ms = {
+            "batch_pageable": timed_upload(lambda: eng.upload_images_batch(slots, ims, wl.K, poses)) * 1e3,
+            "batch_pinned": timed_upload(lambda: eng.upload_images_batch(slots, pinned, wl.K, poses)) * 1e3,
+            "per_keyframe_calls": timed_upload(single, reps=1) * 1e3,
+            "keyframes": len(ks),
+        }
+        for a in pinned:
+            eng.host_free(a)
 
     stats = None if args.no_stats else wl.scan_stats()  # untimed counting variant of K1
 
@@ -478,8 +508,9 @@ def main():
     ms_step = dt / args.steps * 1e3
     value = P * n_total * args.steps / dt / 1e6
     rf, k1_avg_ms = roofline(wl, timing, args.steps,
-                             committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps)
-                             if (world == 1 and not args.noise) else None)
+                             committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps,
+                                               noise=args.noise, outliers=args.outliers)
+                             if world == 1 else None)
     rf_cold, _ = roofline(wl, timing_cold, args.steps, None)
     rf["frac_cold"] = rf_cold["frac"]  # the same K steps after only the W warm-up steps (no pre-warm phase)
     rf["launch_ms_cold"] = rf_cold["launch_ms"]
@@ -508,7 +539,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": workload_name(W, H, args.kfs, N, args.res, args.independent) +
-                        (", i.i.d. uniform u8 noise images" if args.noise else ""),
+                        (", i.i.d. uniform u8 noise images" if args.noise else "") +
+                        (", %d wrong-pose neighbours per keyframe, K1 ONLY stepped (profiling form; `value` is not the "
+                         "path's throughput)" % args.outliers if args.outliers else ""),
             "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" % xdesc,
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
             "parallelism": ("independent x%d" if args.independent else "keyframe-block x%d") % world, "arch": arch,
@@ -547,9 +580,16 @@ def main():
     if args.cpu_kfs > 0 and world == 1:  # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, wl)
     out["gen_s"] = round(wl.t_gen, 2)
-    if t_h2d is not None:
-        out["host_upload_ms_per_keyframe"] = round(t_h2d * 1e3, 4)
-        out["value_pcie_inclusive"] = round(P * n_total / (dt / args.steps + t_h2d * len(pl["own"])) / 1e6, 2)
+    if upload_ms is not None:
+        # the block's keyframes uploaded in one batch call, then the step
+        def incl(ms_kf):
+            return round(P * n_total / (dt / args.steps + ms_kf * 1e-3 * len(pl["own"])) / 1e6, 2)
+        out["host_upload_ms_per_keyframe"] = round(upload_ms["batch_pageable"], 4)
+        out["host_upload"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in upload_ms.items()}
+        out["host_upload"]["unit"] = "ms per keyframe, wall clock incl. the device pre-pass (best of 3)"
+        out["value_pcie_inclusive"] = incl(upload_ms["batch_pageable"])
+        out["value_pcie_inclusive_pinned"] = incl(upload_ms["batch_pinned"])
+        out["value_pcie_inclusive_per_keyframe_calls"] = incl(upload_ms["per_keyframe_calls"])
 
     # ---- the other single-GPU BASELINE workloads, each measured like the headline one ----------------------
     if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs) == ("480p", 64, 20):

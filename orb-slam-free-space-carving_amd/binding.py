@@ -57,6 +57,10 @@ SYMBOLS = [
     ("sdm_upload_image", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p]),
     ("sdm_upload_image_rgb", C.c_int, [_ctx, C.c_int, _u8p, C.c_int, _f32p, _f32p, _f32p]),
     ("sdm_upload_image_device", C.c_int, [_ctx, C.c_int, C.c_void_p, _f32p, _f32p]),
+    ("sdm_upload_images_batch", C.c_int, [_ctx, C.c_int, _ip, C.POINTER(C.c_void_p), _f32p, _f32p]),
+    ("sdm_upload_images_rgb_batch", C.c_int, [_ctx, C.c_int, _ip, C.POINTER(C.c_void_p), C.c_int, _f32p, _f32p, _f32p]),
+    ("sdm_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("sdm_host_free", None, [C.c_void_p]),
     ("sdm_set_pose", C.c_int, [_ctx, C.c_int, _f32p]),
     ("sdm_download_inputs", C.c_int, [_ctx, C.c_int, _u8p, _f32p, _f32p, _f32p]),
     ("sdm_search_fuse", C.c_int, [_ctx, C.c_int, _ip, C.c_int, _ip, _f32p, _f32p, _f32p]),
@@ -89,7 +93,9 @@ SYMBOLS = [
     ("sdm_comm_all_max", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_exchange_compact", C.c_int, [_ctx, C.c_int]),
     ("sdm_exchange_mismatches", C.c_int, [_ctx, _ip]),
+    ("sdm_compact_sources_ready", C.c_int, [_ctx, C.c_int, _ip, _ip]),
     ("sdm_active_count", C.c_int, [_ctx, C.c_int, _ip]),
+    ("sdm_download_active_list", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint), C.c_int, _ip, C.POINTER(C.c_ulonglong)]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_intra_grow_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     ("sdm_epipolar_search", C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -243,6 +249,49 @@ class Engine:
             d, dp = _f32(dist)
             assert len(d) == 5
         self._check(self.lib.sdm_upload_image_rgb(self.ctx, slot, px.ctypes.data_as(_u8p), self.ORDER[order], kp, dp, Tp))
+
+    def _upload_args(self, slots, images, K, Tcw, nbytes):
+        n = len(slots)
+        assert len(images) == n
+        ims = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]  # (a pinned array stays where it is)
+        for im in ims:
+            assert im.size == nbytes, (im.shape, nbytes)
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in ims])
+        sl = (C.c_int * n)(*[int(x) for x in slots])
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float32).reshape(-1, 4), (n, 4)), dtype=np.float32)
+        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(n, 12))
+        return n, sl, ptrs, ims, k, T
+
+    def upload_images_batch(self, slots, images, K, Tcw):
+        """n gray images [H, W] in one call; K: [4] (shared) or [n][4]; Tcw: [n] poses"""
+        n, sl, ptrs, ims, k, T = self._upload_args(slots, images, K, Tcw, self.H * self.W)
+        self._check(self.lib.sdm_upload_images_batch(self.ctx, n, sl, ptrs, k.ctypes.data_as(_f32p), T.ctypes.data_as(_f32p)))
+
+    def upload_images_rgb_batch(self, slots, frames, order, K, dist, Tcw):
+        ch = {0: 3, 1: 3, 2: 4, 3: 4, 4: 1}[self.ORDER[order]]
+        n, sl, ptrs, ims, k, T = self._upload_args(slots, frames, K, Tcw, self.H * self.W * ch)
+        dp = None
+        if dist is not None:
+            d, dp = _f32(dist)
+            assert len(d) == 5
+        self._check(self.lib.sdm_upload_images_rgb_batch(self.ctx, n, sl, ptrs, self.ORDER[order], k.ctypes.data_as(_f32p), dp,
+                                                         T.ctypes.data_as(_f32p)))
+
+    def host_alloc(self, shape, dtype=np.uint8):
+        """a numpy array in pinned host memory (sdm_host_alloc); release with host_free(array)"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.sdm_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("sdm_host_alloc(%d)" % nbytes)
+        a = np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p:
+            self.lib.sdm_host_free(p)
 
     def upload_image_device(self, slot, dev_ptr, K, Tcw):
         k, kp = _f32(K)
@@ -411,10 +460,25 @@ class Engine:
         self._check(self.lib.sdm_exchange_mismatches(self.ctx, C.byref(out)))
         return int(out.value)
 
+    def compact_sources_ready(self, slots):
+        arr = (C.c_int * max(len(slots), 1))(*[int(x) for x in slots])
+        out = C.c_int()
+        self._check(self.lib.sdm_compact_sources_ready(self.ctx, len(slots), arr, C.byref(out)))
+        return bool(out.value)
+
     def active_count(self, slot):
         out = C.c_int()
         self._check(self.lib.sdm_active_count(self.ctx, int(slot), C.byref(out)))
         return int(out.value)
+
+    def active_list(self, slot):
+        """(list of y << 16 | x in raster order, 64-bit hash of the pixel set) of a slot"""
+        n = self.active_count(slot)
+        lst = np.empty(max(n, 1), np.uint32)
+        cnt, h = C.c_int(), C.c_ulonglong()
+        self._check(self.lib.sdm_download_active_list(self.ctx, int(slot), lst.ctypes.data_as(C.POINTER(C.c_uint)), int(lst.size),
+                                                      C.byref(cnt), C.byref(h)))
+        return lst[:cnt.value].copy(), int(h.value)
 
     def comm_all_ok(self, local_ok=True):
         out = C.c_int()

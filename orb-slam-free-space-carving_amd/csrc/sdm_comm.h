@@ -160,9 +160,10 @@ int copy_maps(sdm_ctx* c, int n, const float2* const* src, float2* const* dst, h
 // {rho,sigma} of its list entries, in list order: ~19 % of the pixels on the App. D scene, a fixed `entries` per map on the
 // wire (the list's tail is padding).  Sender: k_pack_lists gathers them; receiver: k_unpack_lists scatters them through
 // ITS list into a plane that is (or is first made) zero elsewhere.
-// A packed map is `entries` values followed by a header (XCHG_HEADER float2, one cache line): the sender's list length.
-// A receiver whose list of that keyframe has another length (its image differs from the sender's) does not scatter the
-// map -- it would land on the wrong pixels -- and counts the mismatch (sdm_exchange_mismatches).
+// A packed map is `entries` values followed by a header (XCHG_HEADER float2, one cache line): the sender's list length and the
+// 64-bit hash of its list (the sum over the listed pixels of a mix of (y << 16 | x), kept per slot since the list was built:
+// sdm_ingest.h).  A receiver whose list of that keyframe differs in length or hash (its image differs from the sender's) does
+// not scatter the map -- it would land on the wrong pixels -- and counts the mismatch (sdm_exchange_mismatches).
 constexpr int XCHG_HEADER = 8;
 struct ListBatch {
     int slot[COPY_BATCH];
@@ -170,12 +171,16 @@ struct ListBatch {
 };
 __global__ __launch_bounds__(BLOCK) void k_pack_lists(ListBatch b, const float2* __restrict__ pool, long long plane, int W,
                                                       const unsigned* __restrict__ act, const int* __restrict__ act_count,
-                                                      int entries)
+                                                      const unsigned long long* __restrict__ act_hash, int entries)
 {
     const int slot = b.slot[blockIdx.y];
     float2* __restrict__ out = b.buf[blockIdx.y];
     const int n = act_count[slot];
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[entries] = make_float2(__int_as_float(n), 0.0f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long h = act_hash[slot];
+        out[entries] = make_float2(__int_as_float(n), __uint_as_float((unsigned)h));
+        out[entries + 1] = make_float2(__uint_as_float((unsigned)(h >> 32)), 0.0f);
+    }
     const unsigned* __restrict__ list = act + (long long)slot * plane;
     const float2* __restrict__ map = pool + (long long)slot * plane;
     for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n; t += gridDim.x * BLOCK) {
@@ -185,12 +190,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack_lists(ListBatch b, const float2*
 }
 __global__ __launch_bounds__(BLOCK) void k_unpack_lists(ListBatch b, float2* __restrict__ pool, long long plane, int W,
                                                         const unsigned* __restrict__ act, const int* __restrict__ act_count,
-                                                        int entries, unsigned* __restrict__ mismatches)
+                                                        const unsigned long long* __restrict__ act_hash, int entries,
+                                                        unsigned* __restrict__ mismatches)
 {
     const int slot = b.slot[blockIdx.y];
     const float2* __restrict__ in = b.buf[blockIdx.y];
     const int n = act_count[slot];
-    if (__float_as_int(in[entries].x) != n) {  // the same for every thread of the map
+    const unsigned long long h = act_hash[slot];
+    const float2 h0 = in[entries], h1 = in[entries + 1];
+    if (__float_as_int(h0.x) != n || __float_as_uint(h0.y) != (unsigned)h ||
+        __float_as_uint(h1.x) != (unsigned)(h >> 32)) {  // the same for every thread of the map
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(mismatches, 1u);
         return;
     }
@@ -213,10 +222,10 @@ int list_kernel(sdm_ctx* c, bool pack, int n, const int* slots, float2* const* b
         }
         if (pack)
             hipLaunchKernelGGL(k_pack_lists, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, c->pool, c->P, c->W, c->d_act,
-                               c->d_act_count, c->xchg_entries);
+                               c->d_act_count, c->d_act_hash, c->xchg_entries);
         else
             hipLaunchKernelGGL(k_unpack_lists, dim3(gx, (unsigned)m), dim3(BLOCK), 0, stream, b, c->pool, c->P, c->W, c->d_act,
-                               c->d_act_count, c->xchg_entries, c->d_xchg_mismatch);
+                               c->d_act_count, c->d_act_hash, c->xchg_entries, c->d_xchg_mismatch);
         HIP_TRY(hipGetLastError());
     }
     return SDM_OK;
@@ -712,7 +721,23 @@ int sdm_exchange_compact(sdm_ctx* c, int entries_per_map)
     return SDM_OK;
 }
 
-// Compact maps whose sender's list length differed from the receiver's (they were NOT scattered; the destination plane
+// Would these slots' maps be accepted as compact sources right now (pipeline maps under the current lambdaG: zero outside
+// their active lists)?  The query form of the check the compact sends make before anything is posted: a driver folds it
+// into its per-pass wire-format agreement, so that a rank whose send sources do not qualify (a map restored with
+// sdm_upload_depth, say) makes ALL ranks use whole maps for the pass instead of failing alone with its peers' receives
+// already posted.  List lengths are not part of the answer (they are what sdm_comm_all_max agrees on).
+int sdm_compact_sources_ready(sdm_ctx* c, int n, const int* slots, int* ready)
+{
+    if (!c || !ready || (n > 0 && !slots)) return fail(SDM_EINVAL, "null argument");
+    *ready = 1;
+    for (int i = 0; i < n; i++) {
+        if (slots[i] < 0 || slots[i] >= c->cfg.max_keyframes) return fail(SDM_EINVAL, "slot out of range");
+        if (!(c->recon_lambdaG[slots[i]] == c->dprm.lambdaG) || !(c->act_lambdaG[slots[i]] == c->dprm.lambdaG)) *ready = 0;
+    }
+    return SDM_OK;
+}
+
+// Compact maps whose sender's list (length or hash) differed from the receiver's (they were NOT scattered; the destination plane
 // keeps what it held): the count since the last call, after waiting for everything queued.  0 on a healthy job -- the lists
 // are a function of the keyframe's image and lambdaG, which sender and receiver share.
 int sdm_exchange_mismatches(sdm_ctx* c, int* count)

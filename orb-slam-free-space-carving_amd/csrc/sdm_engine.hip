@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sdm_c.h"
@@ -79,7 +80,6 @@ struct sdm_ctx {
     unsigned grow_capacity = 0;
     unsigned grow_launch = 0;
     unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
-    int* d_chunk = nullptr;        // per-1024-pixel chunk counts/offsets while a list is built
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
     bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
@@ -87,22 +87,32 @@ struct sdm_ctx {
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
                                        // came from elsewhere, e.g. sdm_upload_depth): K4 may use the list
 
-    // staging for one keyframe
-    uint8_t* h_im_stage[2] = {nullptr, nullptr};  // pinned ring for host images (sdm_upload_image)
-    hipEvent_t stage_done[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};
-    int stage_next = 0;
+    // staging for one keyframe given as planes (sdm_upload_keyframe) and for sdm_download_inputs
     uint8_t* d_im = nullptr;
-    // colour frames (sdm_upload_image_rgb), allocated on first use: a two-deep pinned ring like the gray path's and one
-    // 4P-byte device buffer (the ingest kernel that reads it is stream-ordered before the next frame's copy)
-    uint8_t* d_rgb = nullptr;
-    uint8_t* h_rgb[2] = {nullptr, nullptr};
-    hipEvent_t rgb_done[2] = {nullptr, nullptr};
-    bool rgb_busy[2] = {false, false};
-    int rgb_next = 0;
+    // ---- batched ingest (sdm_ingest.h): two chunk buffers, filled by H2D copies on the upload stream while the compute
+    // stream runs the pre-pass of the other one
+    int ing_cap = 0;  // keyframes per chunk (their gray images together <= 32 MB)
+    struct IngestBuf {
+        uint8_t* d_img = nullptr;       // [ing_cap][P] gray images
+        uint8_t* h_ring = nullptr;      // pinned staging for pageable host images (same size)
+        uint8_t* d_src = nullptr;       // colour frames (sdm_upload_image_rgb*), src_bytes, allocated on first use
+        uint8_t* h_src = nullptr;       // pinned staging for pageable colour frames
+        IngestItem* h_items = nullptr;  // pinned
+        IngestItem* d_items = nullptr;
+        hipEvent_t copied = nullptr;    // this chunk's H2D copies (upload stream) have finished
+        hipEvent_t consumed = nullptr;  // the kernels that read d_img / d_src / d_items (compute stream) have finished
+        bool copied_pending = false, consumed_pending = false;
+    } ing[2];
+    int ing_next = 0;
+    size_t src_bytes = 0;
+    hipStream_t up_stream = nullptr;
+    unsigned long long* d_part = nullptr;      // [ing_cap][ntiles][PART_WORDS] per-tile partial sums
+    unsigned long long* d_seg_mask = nullptr;  // [ing_cap][nseg] lambdaG-gate lane mask of every 64-pixel row segment
+    int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
+    int nseg = 0;                              // H * tiles_x
+    unsigned long long* d_act_hash = nullptr;  // [max_keyframes] hash of the active-pixel set (compact wire header)
     float* d_grad = nullptr;
     float* d_theta = nullptr;
-    unsigned long long* d_sums = nullptr;
     float* d_small = nullptr;  // 16 floats of per-pixel results
 
     // per-call tables: one packed device block + pinned host mirror, staged with a single copy, and the
@@ -194,31 +204,107 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.default_gates = (c->prm.lambdaL == 80.0f && c->prm.lambdaTheta == 45.0f) ? 1 : 0;
 }
 
-// (re)build the active-pixel list of a slot for the current lambdaG; the count comes back asynchronously
-int build_active(sdm_ctx* c, int slot)
+int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+// ---- ingest chunks ---------------------------------------------------------------------------------------------------------
+// chunk buffer b is free: the host may rewrite its pinned blocks (their H2D copies have finished) and the upload stream may
+// overwrite its device blocks once the kernels that read them have finished
+int ingest_acquire(sdm_ctx* c, int b)
 {
-    const int n_chunks = (int)((c->P + ACT_BLOCK - 1) / ACT_BLOCK);
-    const float4* r = c->rec + (long long)slot * c->P;
-    hipLaunchKernelGGL(k_active_count, dim3(n_chunks), dim3(ACT_BLOCK), 0, c->stream, r, c->W, c->H, c->dprm.lambdaG,
-                       c->d_chunk);
-    hipLaunchKernelGGL(k_active_scan, dim3(1), dim3(ACT_BLOCK), 0, c->stream, c->d_chunk, n_chunks,
-                       c->d_act_count + slot);
-    hipLaunchKernelGGL(k_active_write, dim3(n_chunks), dim3(ACT_BLOCK), 0, c->stream, r, c->W, c->H, c->dprm.lambdaG,
-                       c->d_chunk, c->d_act + (long long)slot * c->P);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&c->h_act_count[slot], c->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost,
-                           c->stream));
-    c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
-    if (c->act_lambdaG[slot] == c->act_lambdaG[slot]) {
-        // the slot had a list under another lambdaG: its checked / xyz planes were written through that list and may
-        // be non-zero outside the new one
-        c->chk_sparse[slot] = 0;
-        c->xyz_sparse[slot] = 0;
+    sdm_ctx::IngestBuf& B = c->ing[b];
+    if (B.copied_pending) {
+        HIP_TRY(hipEventSynchronize(B.copied));
+        B.copied_pending = false;
     }
-    c->act_lambdaG[slot] = c->dprm.lambdaG;
+    if (B.consumed_pending) {
+        HIP_TRY(hipStreamWaitEvent(c->up_stream, B.consumed, 0));
+        B.consumed_pending = false;
+    }
+    return SDM_OK;
+}
+// the chunk's item table goes up behind whatever image copies were queued on the upload stream; the compute stream waits
+// for all of it
+int ingest_publish(sdm_ctx* c, int b, int m)
+{
+    sdm_ctx::IngestBuf& B = c->ing[b];
+    HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, c->up_stream));
+    HIP_TRY(hipEventRecord(B.copied, c->up_stream));
+    B.copied_pending = true;
+    HIP_TRY(hipStreamWaitEvent(c->stream, B.copied, 0));
+    return SDM_OK;
+}
+// list lengths of the chunk's slots -> pinned host mirror (one copy when the slots are consecutive)
+int ingest_counts(sdm_ctx* c, int m, const int* slots)
+{
+    bool run = true;
+    for (int i = 1; i < m; i++) run = run && slots[i] == slots[0] + i;
+    if (run) {
+        HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[0]], c->d_act_count + slots[0], sizeof(int) * (size_t)m,
+                               hipMemcpyDeviceToHost, c->stream));
+    } else {
+        for (int i = 0; i < m; i++)
+            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost,
+                                   c->stream));
+    }
+    c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
+    return SDM_OK;
+}
+// the three launches of a chunk on the compute stream (+ k_ingest_batch for colour / distorted frames)
+int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q)
+{
+    sdm_ctx::IngestBuf& B = c->ing[b];
+    const int tiles_x = c->geom.tiles_x, ntiles = c->geom.ntiles;
+    if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, *q);
+    if (from_images)
+        hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P,
+                           c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg);
+    else
+        hipLaunchKernelGGL(k_gate_batch, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P, c->rec,
+                           c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg);
+    hipLaunchKernelGGL(k_prepass_finish, dim3(m), dim3(FIN_BLOCK), 0, c->stream, B.d_items, c->W, c->H, ntiles, c->nseg, c->d_part,
+                       c->d_seg_mask, c->d_seg_off, c->d_meta, c->d_act_count, c->d_theta_bad, c->d_act_hash,
+                       from_images ? 1 : 0);
+    hipLaunchKernelGGL(k_list_write, dim3((c->nseg + BLOCK / 64 - 1) / (BLOCK / 64), m), dim3(BLOCK), 0, c->stream, B.d_items,
+                       tiles_x, c->nseg, c->P, c->d_seg_mask, c->d_seg_off, c->d_act);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(B.consumed, c->stream));
+    B.consumed_pending = true;
+    return SDM_OK;
+}
+
+// (re)build the active-pixel lists of `n` slots from their records for the current lambdaG (sdm_set_params changed it, or
+// the records came from the caller's own planes); the counts come back asynchronously
+int rebuild_lists(sdm_ctx* c, int n, const int* slots)
+{
+    int rc;
+    for (int i0 = 0; i0 < n; i0 += c->ing_cap) {
+        const int m = std::min(c->ing_cap, n - i0);
+        const int b = c->ing_next;
+        c->ing_next ^= 1;
+        if ((rc = ingest_acquire(c, b))) return rc;
+        for (int i = 0; i < m; i++) {
+            IngestItem& it = c->ing[b].h_items[i];
+            memset(&it, 0, sizeof(it));
+            it.slot = slots[i0 + i];
+        }
+        if ((rc = ingest_publish(c, b, m))) return rc;
+        if ((rc = ingest_launch(c, b, m, false, nullptr))) return rc;
+        if ((rc = ingest_counts(c, m, slots + i0))) return rc;
+    }
+    for (int i = 0; i < n; i++) {
+        const int slot = slots[i];
+        if (c->act_lambdaG[slot] == c->act_lambdaG[slot]) {
+            // the slot had a list under another lambdaG: its checked / xyz planes were written through that list and may
+            // be non-zero outside the new one
+            c->chk_sparse[slot] = 0;
+            c->xyz_sparse[slot] = 0;
+        }
+        c->act_lambdaG[slot] = c->dprm.lambdaG;
+    }
     c->epoch++;
     return SDM_OK;
 }
+int build_active(sdm_ctx* c, int slot) { return rebuild_lists(c, 1, &slot); }
 
 // the host mirror of the list lengths is valid after this (uploads leave their read-backs in flight)
 int sync_counts(sdm_ctx* c)
@@ -271,8 +357,6 @@ size_t select_set(sdm_ctx* c, int si, int n_ref, size_t np)
     return words;
 }
 
-int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
-
 // One dispatch stays below 2^30 work-items.  A launch of 2^31 or more (still below HIP's documented 2^32 limit) runs, but
 // not over the whole grid on this stack: K1 over 2048 keyframes of 1920x1080 in ONE launch (14.8 M workgroups x 256 =
 // 3.8e9 work-items) returned wrong maps for keyframe 0 while 1024 keyframes (1.9e9) were right (round 3,
@@ -281,7 +365,10 @@ int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
 template <typename F>
 void for_ref_slices(int n_ref, long long blocks_per_ref, int threads, F&& fn)
 {
-    const long long max_blocks = (1ll << 30) / threads;
+    // (SDM_MAX_DISPATCH_LOG2: debugging knob, read per call -- tools/debug/unsliced_vs_sliced.py)
+    int lg = 30;
+    if (const char* e = getenv("SDM_MAX_DISPATCH_LOG2")) lg = std::max(20, std::min(40, atoi(e)));
+    const long long max_blocks = (1ll << lg) / threads;
     const int per = (int)std::max<long long>(1, std::min<long long>(n_ref, max_blocks / std::max<long long>(blocks_per_ref, 1)));
     for (int first = 0; first < n_ref; first += per) fn(first, std::min(per, n_ref - first));
 }
@@ -328,9 +415,14 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
     int rc;
-    for (int r = 0; r < n_ref; r++)  // lists follow lambdaG (sdm_set_params)
-        if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG))
-            if ((rc = build_active(c, ref_slots[r]))) return rc;
+    {  // lists follow lambdaG (sdm_set_params)
+        std::vector<int> stale;
+        for (int r = 0; r < n_ref; r++)
+            if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG) &&
+                std::find(stale.begin(), stale.end(), ref_slots[r]) == stale.end())
+                stale.push_back(ref_slots[r]);
+        if (!stale.empty() && (rc = rebuild_lists(c, (int)stale.size(), stale.data()))) return rc;
+    }
     if ((rc = sync_counts(c))) return rc;  // callers size their grids from h_act_count
 
     const size_t np = (size_t)n_ref * (size_t)n;
@@ -429,8 +521,8 @@ int push_meta(sdm_ctx* c, int slot, bool keep_istd)
     return SDM_OK;
 }
 
-// a keyframe uploaded into a slot starts with fresh (zero) maps and no stage flags
-int reset_slot(sdm_ctx* c, int slot)
+// a keyframe uploaded into a slot starts with fresh (zero) maps and no stage flags: the host-side bookkeeping ...
+void reset_slot_state(sdm_ctx* c, int slot)
 {
     c->epoch++;
     c->has_depth[slot] = 0;
@@ -439,6 +531,11 @@ int reset_slot(sdm_ctx* c, int slot)
     c->act_lambdaG[slot] = std::nanf("");
     c->chk_sparse[slot] = 1;
     c->xyz_sparse[slot] = 1;
+}
+// ... and the planes (the image paths clear them inside k_prepass_batch instead)
+int reset_slot(sdm_ctx* c, int slot)
+{
+    reset_slot_state(c, slot);
     HIP_TRY(hipMemsetAsync(c->pool + (long long)slot * c->P, 0, sizeof(float2) * c->P, c->stream));
     HIP_TRY(hipMemsetAsync(c->chk + (long long)slot * c->P, 0, sizeof(float) * c->P, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_theta_bad + slot, 0, sizeof(int), c->stream));  // k_pack sets it again if need be
@@ -461,21 +558,6 @@ int pack_staged(sdm_ctx* c, int slot)
                        c->W, c->H, c->rec + (long long)slot * c->P, c->d_theta_bad + slot);
     HIP_TRY(hipGetLastError());
     return SDM_OK;
-}
-
-// gradient pre-pass from c->d_im (or an external device image) into the staging planes + records
-int prepass_and_pack(sdm_ctx* c, int slot, const uint8_t* d_image)
-{
-    hipLaunchKernelGGL(k_gradient, dim3(c->geom.ntiles), dim3(BLOCK), 0, c->stream, d_image, c->W, c->H, c->d_grad,
-                       c->d_theta, c->d_sums);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_istd_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->d_sums, c->geom.ntiles, c->W, c->H,
-                       c->d_meta + slot);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_pack, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, d_image, c->d_grad, c->d_theta,
-                       c->W, c->H, c->rec + (long long)slot * c->P, c->d_theta_bad + slot);
-    HIP_TRY(hipGetLastError());
-    return build_active(c, slot);
 }
 
 template <typename T>
@@ -624,11 +706,30 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         if (hipMemset(c->d_grow_ctr, 0, 2 * sizeof(unsigned)) != hipSuccess)
             return bail(fail(SDM_EHIP, "grow-list counter initialisation failed"));
     }
-    if ((rc = dev_alloc(&c->d_chunk, (size_t)((c->P + ACT_BLOCK - 1) / ACT_BLOCK)))) return bail(rc);
+    {
+        // ingest chunks: as many keyframes as keep a chunk's gray images within 32 MB (64 at 640x480, 16 at 1920x1080)
+        c->nseg = c->H * c->geom.tiles_x;
+        c->ing_cap = (int)std::max<long long>(1, std::min<long long>(std::min(64, K), ((long long)32 << 20) / c->P));
+        c->src_bytes = (size_t)std::max<long long>((long long)c->ing_cap * c->P, 4 * c->P);
+        if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
+        for (int b = 0; b < 2; b++) {
+            sdm_ctx::IngestBuf& B = c->ing[b];
+            if ((rc = dev_alloc(&B.d_img, (size_t)c->ing_cap * c->P)) || (rc = host_alloc(&B.h_ring, (size_t)c->ing_cap * c->P)) ||
+                (rc = dev_alloc(&B.d_items, (size_t)c->ing_cap)) || (rc = host_alloc(&B.h_items, (size_t)c->ing_cap)))
+                return bail(rc);
+            if (hipEventCreateWithFlags(&B.copied, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&B.consumed, hipEventDisableTiming) != hipSuccess)
+                return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+        }
+        if ((rc = dev_alloc(&c->d_part, (size_t)c->ing_cap * c->geom.ntiles * PART_WORDS)) ||
+            (rc = dev_alloc(&c->d_seg_mask, (size_t)c->ing_cap * c->nseg)) ||
+            (rc = dev_alloc(&c->d_seg_off, (size_t)c->ing_cap * c->nseg)) || (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
+            return bail(rc);
+    }
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_sums, 2 * (size_t)c->geom.ntiles))) return bail(rc);  // per-tile {sum, sum of squares}
     if ((rc = dev_alloc(&c->d_small, 16))) return bail(rc);
     if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
     const size_t np = (size_t)K * cfg->max_neighbours;
@@ -644,11 +745,6 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = host_alloc(&c->h_f2, (size_t)c->P))) return bail(rc);
     if ((rc = host_alloc(&c->h_act_count, (size_t)K))) return bail(rc);
     memset(c->h_act_count, 0, sizeof(int) * (size_t)K);
-    for (int b = 0; b < 2; b++) {
-        if ((rc = host_alloc(&c->h_im_stage[b], (size_t)c->P))) return bail(rc);
-        if (hipEventCreateWithFlags(&c->stage_done[b], hipEventDisableTiming) != hipSuccess)
-            return bail(fail(SDM_EHIP, "hipEventCreate failed"));
-    }
 
     // zero-initialised maps, as a fresh KeyFrame's depth_map_/depth_sigma_/SemiDensePointSets_
     if (hipMemsetAsync(c->rec, 0, sizeof(float4) * c->P * K, c->stream) != hipSuccess ||
@@ -657,6 +753,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->d_meta, 0, sizeof(KfMeta) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_act_count, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_theta_bad, 0, sizeof(int) * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_act_hash, 0, sizeof(unsigned long long) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -696,16 +793,26 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_grow_ctr);
     (void)hipFree(c->d_grow_pix);
     (void)hipFree(c->d_grow_val);
-    (void)hipFree(c->d_chunk);
-    (void)hipFree(c->d_im);
-    (void)hipFree(c->d_rgb);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     for (int b = 0; b < 2; b++) {
-        (void)hipHostFree(c->h_rgb[b]);
-        if (c->rgb_done[b]) (void)hipEventDestroy(c->rgb_done[b]);
+        sdm_ctx::IngestBuf& B = c->ing[b];
+        (void)hipFree(B.d_img);
+        (void)hipFree(B.d_src);
+        (void)hipFree(B.d_items);
+        (void)hipHostFree(B.h_ring);
+        (void)hipHostFree(B.h_src);
+        (void)hipHostFree(B.h_items);
+        if (B.copied) (void)hipEventDestroy(B.copied);
+        if (B.consumed) (void)hipEventDestroy(B.consumed);
     }
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    (void)hipFree(c->d_part);
+    (void)hipFree(c->d_seg_mask);
+    (void)hipFree(c->d_seg_off);
+    (void)hipFree(c->d_act_hash);
+    (void)hipFree(c->d_im);
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
-    (void)hipFree(c->d_sums);
     (void)hipFree(c->d_small);
     (void)hipFree(c->d_stats);
     for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
@@ -718,10 +825,6 @@ void sdm_destroy(sdm_ctx* c)
     }
     (void)hipHostFree(c->h_f2);
     (void)hipHostFree(c->h_act_count);
-    for (int b = 0; b < 2; b++) {
-        (void)hipHostFree(c->h_im_stage[b]);
-        if (c->stage_done[b]) (void)hipEventDestroy(c->stage_done[b]);
-    }
     for (auto& sp : c->spans) {
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
@@ -783,41 +886,132 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     return sync_counts(c);  // the caller's (pageable) planes are released on return
 }
 
-int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], const float Tcw[12])
+// ---- image ingest, batched (sdm_ingest.h) ------------------------------------------------------------------------------------
+namespace {
+
+bool host_pinned(const void* p)
 {
-    int rc = check_slot(c, slot, false);
-    if (rc) return rc;
-    if (!im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    if ((rc = reset_slot(c, slot))) return rc;
-    // asynchronous: the image is copied into a pinned ring buffer (the caller's buffer is free on return), every
-    // device step is stream-ordered, and nothing here waits for the GPU unless both ring buffers are in flight
-    const int b = c->stage_next;
-    c->stage_next ^= 1;
-    if (c->stage_busy[b]) {
-        HIP_TRY(hipEventSynchronize(c->stage_done[b]));
-        c->stage_busy[b] = false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary (pageable) host pointer is "invalid value" to the runtime
+        return false;
     }
-    memcpy(c->h_im_stage[b], im, (size_t)c->P);
-    HIP_TRY(hipMemcpyAsync(c->d_im, c->h_im_stage[b], (size_t)c->P, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->stage_done[b], c->stream));
-    c->stage_busy[b] = true;
-    KfMeta& m = c->h_meta[slot];
-    fill_meta(m, K, Tcw);
-    m.uploaded = 1;
-    if ((rc = push_meta(c, slot, true))) return rc;
-    return prepass_and_pack(c, slot, c->d_im);
+    return a.type == hipMemoryTypeHost;
 }
 
-// Tracking.cc:244-257 + 266-271 and Modeler.cc:154-155 on the device: colour order, lens undistortion, gray conversion,
-// then the same pre-pass as sdm_upload_image.
-int sdm_upload_image_rgb(sdm_ctx* c, int slot, const uint8_t* pixels, int order, const float K[4], const float dist[5],
-                         const float Tcw[12])
+// `m` images of `bytes` each into consecutive slots of a pinned block; a few helper threads when it is worth their start-up
+void stage_copy(uint8_t* dst, const uint8_t* const* src, int m, size_t bytes)
 {
-    int rc = check_slot(c, slot, false);
+    const size_t total = (size_t)m * bytes;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = (total >= ((size_t)2 << 20) && hw >= 4) ? std::min(std::min(m, 4), hw / 2) : 1;
+    auto work = [&](int t) {
+        for (int i = t; i < m; i += nt) memcpy(dst + (size_t)i * bytes, src[i], bytes);
+    };
+    if (nt <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
+int check_batch_slots(sdm_ctx* c, int n, const int* slots)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (n < 0 || (n > 0 && !slots)) return fail(SDM_EINVAL, "bad slot list");
+    std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
+    for (int i = 0; i < n; i++) {
+        int rc = check_slot(c, slots[i], false);
+        if (rc) return rc;
+        if (seen[slots[i]]) return fail(SDM_EINVAL, "duplicate slot in one upload batch");
+        seen[slots[i]] = 1;
+    }
+    return SDM_OK;
+}
+
+int ensure_src_buffers(sdm_ctx* c)
+{
+    if (c->ing[0].d_src) return SDM_OK;
+    int rc;
+    for (int b = 0; b < 2; b++) {
+        if ((rc = dev_alloc(&c->ing[b].d_src, c->src_bytes))) return rc;
+        if ((rc = host_alloc(&c->ing[b].h_src, c->src_bytes))) return rc;
+    }
+    return SDM_OK;
+}
+
+// n keyframes from host memory (gray: q == nullptr, P bytes each; else interleaved frames of P * q->channels bytes) or
+// from device memory (on_device: gray only).  Chunk k+1's copies run on the upload stream while chunk k's pre-pass runs
+// on the compute stream.  Pinned host images are copied from where they lie; pageable ones go through the pinned ring.
+int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* images, bool on_device, const IngestParams* q,
+                  const float* K, const float* Tcw)
+{
+    int rc = check_batch_slots(c, n, slots);
     if (rc) return rc;
-    if (!pixels || !K || !Tcw) return fail(SDM_EINVAL, "null input");
-    IngestParams q{};
+    if (n == 0) return SDM_OK;
+    if (!images || !K || !Tcw) return fail(SDM_EINVAL, "null input");
+    for (int i = 0; i < n; i++)
+        if (!images[i]) return fail(SDM_EINVAL, "null image");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (q && (rc = ensure_src_buffers(c))) return rc;
+    const size_t bytes = (size_t)c->P * (q ? q->channels : 1);
+    const int cap = q ? (int)std::max<size_t>(1, std::min<size_t>((size_t)c->ing_cap, c->src_bytes / bytes)) : c->ing_cap;
+    bool direct = false;  // some H2D copy reads the caller's (pinned) memory
+    int last = -1;
+    for (int i0 = 0; i0 < n; i0 += cap) {
+        const int m = std::min(cap, n - i0);
+        const int b = c->ing_next;
+        c->ing_next ^= 1;
+        sdm_ctx::IngestBuf& B = c->ing[b];
+        if ((rc = ingest_acquire(c, b))) return rc;
+        uint8_t* d_dst = q ? B.d_src : B.d_img;
+        uint8_t* h_dst = q ? B.h_src : B.h_ring;
+        for (int i = 0; i < m; i++) {
+            IngestItem& it = B.h_items[i];
+            memset(&it, 0, sizeof(it));
+            it.slot = slots[i0 + i];
+            it.img = on_device ? images[i0 + i] : B.d_img + (size_t)i * c->P;
+            it.src = q ? B.d_src + (size_t)i * bytes : nullptr;
+            fill_meta(it.meta, K + 4 * (size_t)(i0 + i), Tcw + 12 * (size_t)(i0 + i));
+            it.meta.uploaded = 1;
+        }
+        if (!on_device) {
+            int n_pinned = 0;
+            for (int i = 0; i < m; i++) n_pinned += host_pinned(images[i0 + i]) ? 1 : 0;
+            if (n_pinned == m) {
+                for (int i = 0; i < m; i++)
+                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], bytes, hipMemcpyHostToDevice, c->up_stream));
+                direct = true;
+            } else {
+                stage_copy(h_dst, images + i0, m, bytes);
+                HIP_TRY(hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, c->up_stream));
+            }
+        }
+        if ((rc = ingest_publish(c, b, m))) return rc;
+        for (int i = 0; i < m; i++) {
+            const int slot = slots[i0 + i];
+            reset_slot_state(c, slot);
+            c->h_meta[slot] = B.h_items[i].meta;  // (I_stddev lives on the device only)
+            c->act_lambdaG[slot] = c->dprm.lambdaG;
+        }
+        if ((rc = ingest_launch(c, b, m, true, q))) return rc;
+        if ((rc = ingest_counts(c, m, slots + i0))) return rc;
+        last = b;
+    }
+    // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
+    // in place are awaited here (the pre-pass kernels are not)
+    if (direct && last >= 0) {
+        HIP_TRY(hipEventSynchronize(c->ing[last].copied));
+        c->ing[last].copied_pending = false;
+    }
+    return SDM_OK;
+}
+
+int colour_order(int order, IngestParams& q)
+{
     switch (order) {
         case SDM_ORDER_RGB: q.channels = 3; q.r_idx = 0; q.g_idx = 1; q.b_idx = 2; break;
         case SDM_ORDER_BGR: q.channels = 3; q.r_idx = 2; q.g_idx = 1; q.b_idx = 0; break;
@@ -826,54 +1020,70 @@ int sdm_upload_image_rgb(sdm_ctx* c, int slot, const uint8_t* pixels, int order,
         case SDM_ORDER_GRAY: q.channels = 1; break;
         default: return fail(SDM_EINVAL, "unknown colour order");
     }
-    q.fx = K[0]; q.fy = K[1]; q.cx = K[2]; q.cy = K[3];
+    return SDM_OK;
+}
+
+}  // namespace
+
+int sdm_upload_images_batch(sdm_ctx* c, int n, const int* slots, const uint8_t* const* images, const float* K, const float* Tcw)
+{
+    return ingest_images(c, n, slots, images, false, nullptr, K, Tcw);
+}
+
+int sdm_upload_image(sdm_ctx* c, int slot, const uint8_t* im, const float K[4], const float Tcw[12])
+{
+    return ingest_images(c, 1, &slot, &im, false, nullptr, K, Tcw);
+}
+
+// Tracking.cc:244-257 + 266-271 and Modeler.cc:154-155 on the device: colour order, lens undistortion, gray conversion,
+// then the same pre-pass as sdm_upload_image.
+int sdm_upload_images_rgb_batch(sdm_ctx* c, int n, const int* slots, const uint8_t* const* pixels, int order, const float* K,
+                                const float dist[5], const float* Tcw)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (n > 0 && !K) return fail(SDM_EINVAL, "null input");
+    IngestParams q{};
+    int rc = colour_order(order, q);
+    if (rc) return rc;
+    if (n > 0) {  // one camera per batch: the first keyframe's intrinsics undistort every frame
+        q.fx = K[0]; q.fy = K[1]; q.cx = K[2]; q.cy = K[3];
+        for (int i = 1; i < n && dist; i++)
+            if (memcmp(K, K + 4 * (size_t)i, sizeof(float) * 4) != 0)
+                return fail(SDM_EINVAL, "one batch undistorts with one camera: the K of its frames differ");
+    }
     q.undistort = dist != nullptr;
     if (dist) { q.k1 = dist[0]; q.k2 = dist[1]; q.p1 = dist[2]; q.p2 = dist[3]; q.k3 = dist[4]; }
-    if (dist && !(K[0] != 0.0f && K[1] != 0.0f)) return fail(SDM_EINVAL, "zero focal length");
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    if (!c->d_rgb) {
-        if ((rc = dev_alloc(&c->d_rgb, (size_t)c->P * 4))) return rc;
-        for (int b = 0; b < 2; b++) {
-            if ((rc = host_alloc(&c->h_rgb[b], (size_t)c->P * 4))) return rc;
-            HIP_TRY(hipEventCreateWithFlags(&c->rgb_done[b], hipEventDisableTiming));
-        }
-    }
-    if ((rc = reset_slot(c, slot))) return rc;
-    const size_t bytes = (size_t)c->P * q.channels;
-    // asynchronous like sdm_upload_image: the frame is copied into a pinned ring buffer (the caller's buffer is free on
-    // return); the host waits only when both ring buffers are still in flight
-    const int b = c->rgb_next;
-    c->rgb_next ^= 1;
-    if (c->rgb_busy[b]) {
-        HIP_TRY(hipEventSynchronize(c->rgb_done[b]));
-        c->rgb_busy[b] = false;
-    }
-    memcpy(c->h_rgb[b], pixels, bytes);
-    HIP_TRY(hipMemcpyAsync(c->d_rgb, c->h_rgb[b], bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->rgb_done[b], c->stream));
-    c->rgb_busy[b] = true;
-    hipLaunchKernelGGL(k_ingest, dim3(blocks_for(c->P)), dim3(BLOCK), 0, c->stream, c->d_rgb, c->W, c->H, q, c->d_im);
-    HIP_TRY(hipGetLastError());
-    KfMeta& m = c->h_meta[slot];
-    fill_meta(m, K, Tcw);
-    m.uploaded = 1;
-    if ((rc = push_meta(c, slot, true))) return rc;
-    return prepass_and_pack(c, slot, c->d_im);
+    if (dist && n > 0 && !(K[0] != 0.0f && K[1] != 0.0f)) return fail(SDM_EINVAL, "zero focal length");
+    return ingest_images(c, n, slots, pixels, false, &q, K, Tcw);
+}
+
+int sdm_upload_image_rgb(sdm_ctx* c, int slot, const uint8_t* pixels, int order, const float K[4], const float dist[5],
+                         const float Tcw[12])
+{
+    return sdm_upload_images_rgb_batch(c, 1, &slot, &pixels, order, K, dist, Tcw);
 }
 
 int sdm_upload_image_device(sdm_ctx* c, int slot, const void* d_im, const float K[4], const float Tcw[12])
 {
-    int rc = check_slot(c, slot, false);
+    const uint8_t* im = (const uint8_t*)d_im;
+    int rc = ingest_images(c, 1, &slot, &im, true, nullptr, K, Tcw);
     if (rc) return rc;
-    if (!d_im || !K || !Tcw) return fail(SDM_EINVAL, "null input");
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    if ((rc = reset_slot(c, slot))) return rc;
-    KfMeta& m = c->h_meta[slot];
-    fill_meta(m, K, Tcw);
-    m.uploaded = 1;
-    if ((rc = push_meta(c, slot, true))) return rc;
-    if ((rc = prepass_and_pack(c, slot, (const uint8_t*)d_im))) return rc;
     return sync_counts(c);  // the caller's device image has been consumed on return
+}
+
+void* sdm_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void sdm_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
@@ -967,6 +1177,20 @@ int sdm_active_count(sdm_ctx* c, int slot, int* count)
         if ((rc = build_active(c, slot))) return rc;
     if ((rc = sync_counts(c))) return rc;
     *count = c->h_act_count[slot];
+    return SDM_OK;
+}
+
+int sdm_download_active_list(sdm_ctx* c, int slot, unsigned* list, int capacity, int* count, unsigned long long* hash)
+{
+    int n = 0;
+    int rc = sdm_active_count(c, slot, &n);
+    if (rc) return rc;
+    if (count) *count = n;
+    if (list && capacity < n) return fail(SDM_EINVAL, "list buffer too small");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (list && n > 0)
+        HIP_TRY(hipMemcpy(list, c->d_act + (long long)slot * c->P, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost));
+    if (hash) HIP_TRY(hipMemcpy(hash, c->d_act_hash + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return SDM_OK;
 }
 
@@ -1162,6 +1386,8 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd, true);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
+    if (const char* e = getenv("SDM_DEBUG_SYNC_K1"))  // debugging knob (tools/debug/unsliced_vs_sliced.py)
+        if (atoi(e) == 1) HIP_TRY(hipStreamSynchronize(c->stream));
     if ((rc = run_intra_lists(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
     for (int r = 0; r < n_ref; r++) {
         c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244

@@ -12,17 +12,13 @@
 // keyframes read the same neighbour-image region from that XCD's L2 instead of re-fetching it.
 #pragma once
 #include "sdm_device.h"
+#include "sdm_ingest.h"
 
 namespace sdm {
 
-constexpr int TILE_W = 64;
-constexpr int TILE_H = 16;
-constexpr int TILE_PX = TILE_W * TILE_H;  // 1024
-constexpr int BLOCK = 256;
 #ifndef SDM_INTRA_COMPACT
 #define SDM_INTRA_COMPACT 1  // K2/K3 on pipeline maps through a compact result array (0: through a scratch plane, the round-2 form)
 #endif
-constexpr int PX_PER_THREAD = TILE_PX / BLOCK;  // 4
 
 struct TileGeom {
     int W, H, tiles_x, tiles_y, ntiles;
@@ -83,200 +79,6 @@ __device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], uns
     for (int i = 0; i < PX_PER_THREAD; i++)
         if (f[i]) act[off[i] + pre[i]] = (unsigned short)(i * BLOCK + tid);
     return total;
-}
-
-constexpr int HALO_W_K0 = TILE_W + 2;
-constexpr int HALO_H_K0 = TILE_H + 2;
-
-// ---- K(-1): image ingest -- what the fork does to a camera frame before the path sees it --------------------
-// src/Tracking.cc:266-271 undistorts the (colour) frame with cv::undistort(im, imu, mK, mDistCoef) and hands it to
-// Modeler::AddFrameImage, which keeps it 3-channel (src/Modeler/Modeler.cc:1496-1514); the Modeler converts it to
-// gray with cvtColor(CV_RGB2GRAY) where it uses it (src/Modeler/Modeler.cc:154-155); Tracking's own gray image
-// (for ORB) comes from cvtColor(RGB/BGR/RGBA/BGRA -> GRAY), src/Tracking.cc:244-257.
-// One thread per OUTPUT pixel, as cv::undistort does it: the distorted source position in double
-// (initUndistortRectifyMap with R = I and the same camera matrix), rounded to the 1/32-pixel fixed-point map
-// (CV_16SC2 + CV_16UC1, INTER_BITS = 5), bilinear remap in 15-bit fixed point with a constant zero border, then
-// the 8-bit RGB->gray fixed-point weights 4899/9617/1868 >> 14.  OpenCV is absent from the image: this is the
-// published algorithm restated from memory -- PARITY UNPINNED; the oracle states the same
-// arithmetic and the two agree bit for bit.
-struct IngestParams {
-    double fx, fy, cx, cy;
-    double k1, k2, p1, p2, k3;
-    int undistort;  // 0: dist == NULL (copy / grey-convert only)
-    int channels;   // 1, 3 or 4 interleaved bytes per pixel
-    int r_idx, g_idx, b_idx;  // byte index of R, G, B inside a pixel
-};
-
-__device__ __forceinline__ int ingest_gray(int r, int g, int b)
-{
-    return (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;  // RGB2Gray<uchar>: R2Y, G2Y, B2Y, yuv_shift = 14
-}
-
-__global__ __launch_bounds__(BLOCK) void k_ingest(const uint8_t* __restrict__ src, int W, int H, IngestParams q,
-                                                  uint8_t* __restrict__ gray)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= W * H) return;
-    const int v = i / W, u = i - v * W;
-    const int ch = q.channels;
-    if (!q.undistort) {
-        const uint8_t* px = src + (size_t)i * ch;
-        gray[i] = (uint8_t)(ch == 1 ? px[0] : ingest_gray(px[q.r_idx], px[q.g_idx], px[q.b_idx]));
-        return;
-    }
-    const double x = ((double)u - q.cx) / q.fx, y = ((double)v - q.cy) / q.fy;
-    const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
-    const double kr = 1 + ((q.k3 * r2 + q.k2) * r2 + q.k1) * r2;
-    const double xd = x * kr + q.p1 * _2xy + q.p2 * (r2 + 2 * x2);
-    const double yd = y * kr + q.p1 * (r2 + 2 * y2) + q.p2 * _2xy;
-    const double us = q.fx * xd + q.cx, vs = q.fy * yd + q.cy;
-    // saturate_cast<int>(double) = round half to even, clamped; a NaN position lands outside the image
-    double fu = rint(us * 32.0), fv = rint(vs * 32.0);
-    if (!(fu > -2147483648.0)) fu = -2147483648.0;
-    if (!(fv > -2147483648.0)) fv = -2147483648.0;
-    if (fu > 2147483647.0) fu = 2147483647.0;
-    if (fv > 2147483647.0) fv = 2147483647.0;
-    const int iu = (int)fu, iv = (int)fv;
-    const int sx = iu >> 5, sy = iv >> 5, a = iu & 31, b = iv & 31;
-    const int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
-    int acc[3] = {0, 0, 0};
-    const int idx[3] = {ch == 1 ? 0 : q.r_idx, ch == 1 ? 0 : q.g_idx, ch == 1 ? 0 : q.b_idx};
-    const int nc = ch == 1 ? 1 : 3;
-    for (int t = 0; t < 4; t++) {
-        const int yy = sy + (t >> 1), xx = sx + (t & 1);
-        const int w = t == 0 ? w00 : (t == 1 ? w01 : (t == 2 ? w10 : w11));
-        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;  // BORDER_CONSTANT, value 0
-        const uint8_t* px = src + ((size_t)yy * W + xx) * ch;
-        for (int c = 0; c < nc; c++) acc[c] += w * (int)px[idx[c]];
-    }
-    int val[3];
-    for (int c = 0; c < nc; c++) val[c] = (acc[c] + (1 << 14)) >> 15;  // FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS>
-    gray[i] = (uint8_t)(ch == 1 ? val[0] : ingest_gray(val[0], val[1], val[2]));
-}
-
-// ---- K0: input pre-pass ---------------------------------------------------------------------------
-// Scharr/32 gradient, magnitude, fastAtan2 phase (the pre-processing PM.cc assumes on KeyFrame:
-// GradImg / GradTheta) + exact integer sums for I_stddev.
-__global__ __launch_bounds__(BLOCK) void k_gradient(const uint8_t* __restrict__ im, int W, int H,
-                                                    float* __restrict__ grad, float* __restrict__ theta,
-                                                    unsigned long long* __restrict__ sums)
-{
-    // one 64x16 tile per workgroup, staged with its replicated 1-px border in LDS
-    __shared__ uint8_t t[HALO_H_K0][HALO_W_K0];
-    const int tiles_x = (W + TILE_W - 1) / TILE_W;
-    const int tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
-    for (int i = threadIdx.x; i < HALO_H_K0 * HALO_W_K0; i += BLOCK) {
-        int hy = i / HALO_W_K0, hx = i - hy * HALO_W_K0;
-        int x = min(max(tx0 + hx - 1, 0), W - 1), y = min(max(ty0 + hy - 1, 0), H - 1);
-        t[hy][hx] = im[y * W + x];
-    }
-    __syncthreads();
-    unsigned long long s = 0, sq = 0;
-#pragma unroll
-    for (int i = 0; i < PX_PER_THREAD; i++) {
-        int L = i * BLOCK + threadIdx.x;
-        int lx = L & (TILE_W - 1), ly = L >> 6;
-        int x = tx0 + lx, y = ty0 + ly;
-        if (x < W && y < H) {
-            int a00 = t[ly][lx], a01 = t[ly][lx + 1], a02 = t[ly][lx + 2];
-            int a10 = t[ly + 1][lx], a11 = t[ly + 1][lx + 1], a12 = t[ly + 1][lx + 2];
-            int a20 = t[ly + 2][lx], a21 = t[ly + 2][lx + 1], a22 = t[ly + 2][lx + 2];
-            int sx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
-            int sy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
-            float gx = (float)sx * (1.0f / 32.0f), gy = (float)sy * (1.0f / 32.0f);
-            float xx = gx * gx, yy = gy * gy;
-            grad[y * W + x] = sqrtf(xx + yy);
-            theta[y * W + x] = fast_atan2_deg(gy, gx);
-            s += (unsigned long long)a11;
-            sq += (unsigned long long)(a11 * a11);
-        }
-    }
-    // per-tile partial sums (integers: any order gives the same total); same-address atomics from every wave
-    // serialised the whole kernel (34 us at 640x480), so each workgroup writes its own pair instead
-    __shared__ unsigned long long wsum[2][BLOCK / 64];
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_down(s, o);
-        sq += __shfl_down(sq, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        wsum[0][threadIdx.x >> 6] = s;
-        wsum[1][threadIdx.x >> 6] = sq;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        unsigned long long tot = 0;
-        for (int w = 0; w < BLOCK / 64; w++) tot += wsum[threadIdx.x][w];
-        sums[2 * blockIdx.x + threadIdx.x] = tot;
-    }
-}
-
-// I_stddev = population sigma of im (PM.cc:457) from the per-tile sums; one workgroup
-__global__ __launch_bounds__(BLOCK) void k_istd_finish(const unsigned long long* __restrict__ sums, int ntiles, int W,
-                                                       int H, KfMeta* meta)
-{
-    __shared__ unsigned long long wsum[2][BLOCK / 64];
-    unsigned long long s = 0, sq = 0;
-    for (int i = threadIdx.x; i < ntiles; i += BLOCK) {
-        s += sums[2 * i];
-        sq += sums[2 * i + 1];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_down(s, o);
-        sq += __shfl_down(sq, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        wsum[0][threadIdx.x >> 6] = s;
-        wsum[1][threadIdx.x >> 6] = sq;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long ts = 0, tq = 0;
-        for (int w = 0; w < BLOCK / 64; w++) {
-            ts += wsum[0][w];
-            tq += wsum[1][w];
-        }
-        double n = (double)W * (double)H;
-        double mean = (double)ts / n;
-        double var = (double)tq / n - mean * mean;
-        if (var < 0) var = 0;
-        meta->I_stddev = (float)sqrt(var);
-    }
-}
-
-// pack im/grad/theta planes into the 16-byte search records (layout: sdm_device.h)
-// theta_bad: set when any GradTheta value lies outside [0,360] (or is NaN): the slot's pairs then keep the
-// per-candidate precondition of the closed-form angle gates (PairConst::clean).  The device pre-pass (fastAtan2) never
-// produces such a value; a caller's own planes (sdm_upload_keyframe) may.
-__global__ __launch_bounds__(BLOCK) void k_pack(const uint8_t* __restrict__ im, const float* __restrict__ grad,
-                                                const float* __restrict__ theta, int W, int H,
-                                                float4* __restrict__ rec, int* __restrict__ theta_bad)
-{
-    int idx = blockIdx.x * BLOCK + threadIdx.x;
-    bool bad = false;
-    if (idx < W * H) {
-        int y = idx / W;
-        bool below = (y + 1 < H);
-        unsigned bits = (unsigned)im[idx] | ((below ? (unsigned)im[idx + W] : 0u) << 8);
-        float4 r;
-        r.x = grad[idx];
-        r.y = theta[idx];
-        r.z = below ? grad[idx + W] : 0.0f;
-        r.w = __uint_as_float(bits);
-        rec[idx] = r;
-        bad = !(r.y >= 0.0f && r.y <= 360.0f);
-    }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(theta_bad, 1);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_unpack(const float4* __restrict__ rec, int n, uint8_t* __restrict__ im,
-                                                  float* __restrict__ grad, float* __restrict__ theta)
-{
-    int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
-    float4 r = rec[idx];
-    im[idx] = (uint8_t)(__float_as_uint(r.w) & 0xffu);
-    grad[idx] = r.x;
-    theta[idx] = r.y;
 }
 
 // ---- per-batch constant tables ----------------------------------------------------------------------
@@ -347,88 +149,6 @@ __global__ void k_ref_setup(const KfMeta* __restrict__ meta, const int* __restri
     rc.maxd = 0.f;
     rc.act_count = act_counts[ref_slots[r]];
     refs[r] = rc;
-}
-
-// ---- active-pixel lists ------------------------------------------------------------------------------------
-// The reference skips every pixel with GradImg < lambdaG (PM.cc:201), ~80 % of an image, and every
-// later stage only ever touches the survivors.  That set depends on the keyframe's own image only,
-// so it is built ONCE when the keyframe is uploaded: act[] holds (y << 16 | x) of the inset pixels
-// that pass the gate, in raster order (one workgroup per keyframe, deterministic).
-constexpr int ACT_BLOCK = 1024;
-__device__ __forceinline__ bool act_flag(const float4* __restrict__ rec, int W, int H, float lambdaG, int idx,
-                                         int& x, int& y)
-{
-    if (idx >= W * H) return false;
-    y = idx / W;
-    x = idx - y * W;
-    if (!(x >= 2 && x < W - 2 && y >= 2 && y < H - 2)) return false;  // PM.cc:198-199
-    return !(rec[idx].x < lambdaG);                                   // PM.cc:201
-}
-// pass 1: active pixels per 1024-pixel chunk
-__global__ __launch_bounds__(ACT_BLOCK) void k_active_count(const float4* __restrict__ rec, int W, int H,
-                                                            float lambdaG, int* __restrict__ chunk_count)
-{
-    __shared__ int wsum[ACT_BLOCK / 64];
-    int x, y;
-    const bool f = act_flag(rec, W, H, lambdaG, blockIdx.x * ACT_BLOCK + threadIdx.x, x, y);
-    unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < ACT_BLOCK / 64; w++) tot += wsum[w];
-        chunk_count[blockIdx.x] = tot;
-    }
-}
-// pass 2: exclusive scan of the chunk counts (one workgroup; <= 2^20 chunks is far beyond any image)
-__global__ __launch_bounds__(ACT_BLOCK) void k_active_scan(int* __restrict__ chunk_count, int n_chunks,
-                                                           int* __restrict__ total)
-{
-    __shared__ int part[ACT_BLOCK];
-    const int tid = threadIdx.x;
-    const int per = (n_chunks + ACT_BLOCK - 1) / ACT_BLOCK;
-    int s = 0;
-    for (int i = 0; i < per; i++) {
-        int k = tid * per + i;
-        if (k < n_chunks) s += chunk_count[k];
-    }
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < ACT_BLOCK; i++) {
-            int v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-    __syncthreads();
-    int run = part[tid];
-    for (int i = 0; i < per; i++) {
-        int k = tid * per + i;
-        if (k < n_chunks) {
-            int v = chunk_count[k];
-            chunk_count[k] = run;
-            run += v;
-        }
-    }
-}
-// pass 3: write the list in raster order
-__global__ __launch_bounds__(ACT_BLOCK) void k_active_write(const float4* __restrict__ rec, int W, int H,
-                                                            float lambdaG, const int* __restrict__ chunk_off,
-                                                            unsigned* __restrict__ act)
-{
-    __shared__ int wsum[ACT_BLOCK / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int x = 0, y = 0;
-    const bool f = act_flag(rec, W, H, lambdaG, blockIdx.x * ACT_BLOCK + tid, x, y);
-    unsigned long long m = __ballot(f);
-    if (lane == 0) wsum[wave] = __popcll(m);
-    __syncthreads();
-    int off = chunk_off[blockIdx.x];
-    for (int w = 0; w < wave; w++) off += wsum[w];
-    if (f) act[off + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)y << 16) | (unsigned)x;
 }
 
 // zero the depth maps of a batch's reference keyframes (a fresh depth_map_/depth_sigma_)
@@ -853,13 +573,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_fuse_open(OpenList open_list, int 
         for (int o = 32; o > 0; o >>= 1) n_fused += __shfl_down(n_fused, o);
         if ((tid & 63) == 0 && n_fused) atomicAdd(&stats[4], n_fused);
     }
-}
-
-// per-slot metadata written in stream order (80 bytes as a kernel argument: no copy, no host synchronisation)
-__global__ void k_set_meta(KfMeta* __restrict__ dst, KfMeta m, int keep_istd)
-{
-    if (keep_istd) m.I_stddev = dst->I_stddev;
-    *dst = m;
 }
 
 // ---- shared halo loader for the 3x3 stencil kernels -----------------------------------------------------

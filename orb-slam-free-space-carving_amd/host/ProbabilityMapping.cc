@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <string>
 
 #include <unistd.h>
@@ -624,17 +625,18 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
     for (int i = 0; i < n_all && local_ok; i++)
         if (needed[i] && (slot[i] = SlotOf(all[i])) < 0) local_ok = false;
     if (local_ok) {
-        // own keyframes reconstructed in an earlier pass answer with the map they have (the host copy, if the device
-        // slot was recycled); a keyframe without a map is never marked: nobody's plan reads it (PlanBlock)
-        std::vector<int> s;
-        for (int i = first; i < first + count; i++)
-            if (all[i]->semidense_flag_) {
-                PushDepth(all[i], slot[i]);
-                s.push_back(slot[i]);
+        // own keyframes reconstructed in an earlier pass answer with the map they have.  While the device slot still holds
+        // that map nothing is touched (it stays a pipeline map the compact exchange accepts); a slot that was recycled gets
+        // the host copy back -- the reconstructed or the checked map, both zero outside the keyframe's pixel list
+        // (PM.cc:201, 662) -- and is declared a pipeline map again.  A keyframe without a map is never marked: nobody's
+        // plan reads it (PlanBlock)
+        for (int i = first; i < first + count && local_ok; i++) {
+            if (!all[i]->semidense_flag_ || depth_on_device_[all[i]]) continue;
+            PushDepth(all[i], slot[i]);
+            if (!depth_on_device_[all[i]] || sdm_assume_pipeline_maps(ctx_, 1, &slot[i]) != SDM_OK) {
+                report("SemiDenseReconBlock");
+                local_ok = false;
             }
-        if (!s.empty() && sdm_mark_depth_present(ctx_, (int)s.size(), s.data()) != SDM_OK) {
-            report("SemiDenseReconBlock");
-            local_ok = false;
         }
     }
     int all_ok = 0;
@@ -654,13 +656,25 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
             int cnt = 0;
             if (needed[i] && sdm_active_count(ctx_, slot[i], &cnt) == SDM_OK) longest = std::max(longest, cnt);
         }
+        if (opt_.exchange_compact) {
+            // ... and every map this rank sends must qualify as a compact source: the ones it reconstructs in this pass do
+            // by construction, the ones from earlier passes are asked about.  A rank that cannot says so through the same
+            // all-reduce (a "longest list" no wire format can hold): ALL ranks then move whole maps in this pass.
+            std::vector<int> old_src;
+            for (int j : plan.send_kf)
+                if (!plan.recon_all[j]) old_src.push_back(slot[j]);
+            int ready = 1;
+            if (!old_src.empty() && sdm_compact_sources_ready(ctx_, (int)old_src.size(), old_src.data(), &ready) != SDM_OK) ready = 0;
+            if (!ready) longest = std::numeric_limits<int>::max() / 2;
+        }
         if (sdm_comm_all_max(ctx_, longest, &all_longest) != SDM_OK) {
             report("SemiDenseReconBlock");
             return;
         }
         if (opt_.exchange_compact) {
-            entries = (all_longest + 63) / 64 * 64;
-            if (entries * 2 > all[first]->im_.cols * all[first]->im_.rows) entries = 0;
+            const long long P = (long long)all[first]->im_.cols * all[first]->im_.rows;
+            const long long e = ((long long)all_longest + 63) / 64 * 64;
+            entries = (e * 2 > P) ? 0 : (int)e;
         }
         if (sdm_exchange_compact(ctx_, entries) != SDM_OK) {
             report("SemiDenseReconBlock");
@@ -703,7 +717,9 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
     // From here to sdm_exchange_wait this rank takes part in the exchange WHATEVER happens locally: a failed
     // reconstruction still posts the planned sends (of whatever the slots hold) and receives, and is reported after
     bool ok = run_recon(true);  // the keyframes other ranks read first ...
-    if (!ok && !send_slot.empty()) (void)sdm_mark_depth_present(ctx_, (int)send_slot.size(), send_slot.data());
+    // (has_depth + "pipeline map" keep the compact send's own precondition check from failing on this rank alone; what
+    // the slots hold is sent, and the pass is voided for every rank by the agreement at its end)
+    if (!ok && !send_slot.empty()) (void)sdm_assume_pipeline_maps(ctx_, (int)send_slot.size(), send_slot.data());
     if (sdm_exchange_halo_begin(ctx_, (int)send_peer.size(), send_peer.data(), send_slot.data(), (int)recv_peer.size(),
                                 recv_peer.data(), recv_slot.data()) != SDM_OK) {
         report("SemiDenseReconBlock");  // argument / state errors are the same on every rank (replicated plan); an RCCL
@@ -736,8 +752,34 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         report("SemiDenseReconBlock");
         ok = false;
     }
-    if (!ok) return;
-    checked = checked && run_check(true);
+    checked = ok && checked && run_check(true);
+    // a compact map whose list differs from this rank's list of that keyframe was refused by the receiver (its plane is
+    // not the peer's map): the checks that read it are void
+    int refused = 0;
+    if (world > 1 && sdm_exchange_mismatches(ctx_, &refused) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        ok = false;
+    }
+    if (refused > 0) {
+        std::cerr << "ProbabilityMapping::SemiDenseReconBlock: " << refused << " received map(s) refused (the sender's pixel "
+                  << "list differs from this rank's): pass voided" << std::endl;
+        ok = false;
+    }
+    // ---- the pass counts for everybody or for nobody: the stage flags are REPLICATED state (the next pass's plans are
+    // derived from them on every rank and must pair up), so they are set only when every rank finished its share; after a
+    // local failure anywhere they stay as they were on ALL ranks and the pass can be repeated
+    int pass_ok = 0;
+    if (sdm_comm_all_ok(ctx_, (ok && checked) ? 1 : 0, &pass_ok) != SDM_OK) {
+        report("SemiDenseReconBlock");
+        return;
+    }
+    if (!pass_ok) {
+        if (ok && checked)
+            std::cerr << "ProbabilityMapping::SemiDenseReconBlock: another rank failed in this pass; no flags set" << std::endl;
+        // the device maps this pass wrote are not the keyframes' maps: the next pass starts from the host copies
+        for (size_t a = 0; a < refs.size(); a++) depth_on_device_[all[refs[a]]] = 0;
+        return;
+    }
     // the maps as SemiDenseRecon left them (PM.cc:244)
     for (size_t a = 0; a < refs.size(); a++) {
         sdm::KeyFrame* kf = all[refs[a]];
@@ -745,7 +787,6 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         depth_on_device_[kf] = 1;
         kf->semidense_flag_ = true;
     }
-    if (!checked) return;
     for (size_t a = 0; a < plan.check.size(); a++) {
         sdm::KeyFrame* kf = all[plan.check[a]];
         if (sdm_download_checked(ctx_, check_slot[a], kf->depth_map_.ptr()) != SDM_OK ||
@@ -754,9 +795,8 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         depth_on_device_[kf] = 0;  // the host map is now the CHECKED one; the device pool still holds the snapshot
         kf->interKF_depth_flag_ = true;  // PM.cc:306
     }
-    // keep the stage flags REPLICATED: what the other ranks reconstructed / checked in this pass (their maps live on
-    // their GPUs; this rank's copies of those keyframes carry only the flags).  The next pass's plan is derived from
-    // these flags on every rank, so they must not depend on who did the work.
+    // what the other ranks reconstructed / checked in this pass (their maps live on their GPUs; this rank's copies of
+    // those keyframes carry only the flags)
     for (int i = 0; i < n_all; i++) {
         if (plan.recon_all[i]) all[i]->semidense_flag_ = true;
         if (plan.check_all[i]) all[i]->interKF_depth_flag_ = true;

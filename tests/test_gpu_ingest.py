@@ -2,6 +2,8 @@
 src/Tracking.cc:244-257, 266-271, src/Modeler/Modeler.cc:154-155) against the oracle's restatement, bit for bit --
 the gray image, the derived GradImg / GradTheta / I_stddev, and the whole path run from colour frames.
 PARITY UNPINNED for the OpenCV pieces (absent from the image): both sides state the same published algorithm."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,14 @@ from common import Sequence, assert_bit_equal, oracle_inter, oracle_pipeline
 from test_oracle_ingest import TUM1_DIST, TUM1_K
 
 pytestmark = pytest.mark.gpu
+
+
+def _fp(a):
+    a = np.ascontiguousarray(a, np.float32)
+    _fp.keep = a
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
 EYE = np.float32([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])
 
 
@@ -78,3 +88,105 @@ def test_whole_path_from_colour_frames(pkg, oracle, gpu_ok):
         kept += int((chk[k] > 1e-6).sum())
     assert kept > 500
     eng.close()
+
+
+def np_active_list(grad, lambdaG=8.0):
+    """PM.cc:198-201 restated: inset pixels with GradImg >= lambdaG, raster order, as (y << 16 | x)"""
+    H, W = grad.shape
+    m = ~(grad < np.float32(lambdaG))
+    m[:2] = m[-2:] = False
+    m[:, :2] = m[:, -2:] = False
+    ys, xs = np.nonzero(m)
+    return (ys.astype(np.uint32) << 16) | xs.astype(np.uint32)
+
+
+def np_list_hash(lst):
+    """the compact wire header's hash (csrc/sdm_ingest.h list_hash_term): sum of SplitMix64-finalised (y << 16 | x)"""
+    z = lst.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return int(z.sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("W,H,n_kf", [(160, 120, 8), (75, 53, 5), (640, 480, 70)])
+def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf):
+    """sdm_upload_images_batch (one launch of each pre-pass kernel over (keyframe, tile), chunked, H2D on the upload
+    stream; pageable AND pinned sources, non-consecutive slots) against one sdm_upload_image call per keyframe and
+    against the oracle's pre-pass: records, I_stddev, the active-pixel lists and their hashes, bit for bit."""
+    rng = np.random.default_rng(W * 31 + n_kf)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ims = [np.clip(127 + 90 * np.sin(xx / (5.0 + k)) * np.cos(yy / 4.0) + rng.integers(-25, 25, (H, W)), 0, 255).astype(np.uint8)
+           for k in range(n_kf)]
+    K = TUM1_K * np.float32(W / 640.0)
+    poses = [EYE + np.float32(0.01 * k) * np.float32([[0, 0, 0, 1], [0, 0, 0, 0], [0, 0, 0, 0]]) for k in range(n_kf)]
+    n_slots = 2 * n_kf + 3
+    one, bat = pkg.Engine(W, H, n_slots), pkg.Engine(W, H, n_slots)
+    slots = [(7 * k + 3) % n_slots for k in range(n_kf)]  # scattered, not consecutive
+    assert len(set(slots)) == n_kf
+    for k in range(n_kf):
+        one.upload_image(slots[k], ims[k], K, poses[k])
+    # dirty planes first: the batch path clears depth / checked / point planes inside its pre-pass kernel
+    for s in slots[:3]:
+        bat.upload_image(s, ims[0], K, EYE)
+        bat.upload_depth(s, np.full((H, W), 0.7, np.float32), np.full((H, W), 0.1, np.float32))
+    pinned = [bat.host_alloc((H, W)) for _ in range(n_kf)]
+    for k in range(n_kf):
+        pinned[k][...] = ims[k]
+    half = n_kf // 2
+    bat.upload_images_batch(slots[:half], pinned[:half], K, poses[:half])      # read in place by the copy engine
+    bat.upload_images_batch(slots[half:], ims[half:], K, poses[half:])         # pageable: through the pinned ring
+    for k in list(range(min(n_kf, 6))) + [n_kf - 1]:
+        a, b = one.download_inputs(slots[k]), bat.download_inputs(slots[k])
+        assert (a[0] == b[0]).all() and (a[0] == ims[k]).all()
+        assert_bit_equal(a[1], b[1], "GradImg kf %d" % k)
+        assert_bit_equal(a[2], b[2], "GradTheta kf %d" % k)
+        assert np.float32(a[3]) == np.float32(b[3])
+        wg, wt, ws = oracle.gradient_prepass(ims[k])
+        assert_bit_equal(b[1], wg, "GradImg vs oracle kf %d" % k)
+        assert_bit_equal(b[2], wt, "GradTheta vs oracle kf %d" % k)
+        assert np.float32(b[3]) == np.float32(ws)
+        la, ha = one.active_list(slots[k])
+        lb, hb = bat.active_list(slots[k])
+        want = np_active_list(wg)
+        assert (la == want).all() and (lb == want).all() and la.size == want.size
+        assert ha == hb == np_list_hash(want)
+        r, s = bat.download_depth(slots[k])
+        assert not r.any() and not s.any(), "a new keyframe starts with zero maps"
+        assert not bat.download_checked(slots[k]).any()
+    # lists follow lambdaG: rebuilt in one batch from the records
+    one.set_params(lambdaG=14.0)
+    bat.set_params(lambdaG=14.0)
+    for k in (0, n_kf - 1):
+        want = np_active_list(oracle.gradient_prepass(ims[k])[0], 14.0)
+        for e in (one, bat):
+            l, h = e.active_list(slots[k])
+            assert (l == want).all() and h == np_list_hash(want)
+    assert bat.lib.sdm_upload_images_batch(bat.ctx, 2, (C.c_int * 2)(1, 1), (C.c_void_p * 2)(pinned[0].ctypes.data, pinned[1].ctypes.data),
+                                           _fp(np.tile(K, 2)), _fp(np.tile(EYE.reshape(12), 2))) == 1  # duplicate slot
+    for p in pinned:
+        bat.host_free(p)
+    one.close()
+    bat.close()
+
+
+def test_rgb_batch_equals_single_uploads(pkg, oracle, gpu_ok):
+    W, H, n_kf = 160, 120, 9
+    rng = np.random.default_rng(5)
+    K = TUM1_K * np.float32(W / 640.0)
+    frames = [rng.integers(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(n_kf)]
+    poses = [EYE] * n_kf
+    one, bat = pkg.Engine(W, H, n_kf), pkg.Engine(W, H, n_kf)
+    for dist in (TUM1_DIST, None):
+        for k in range(n_kf):
+            one.upload_image_rgb(k, frames[k], "bgr", K, dist, EYE)
+        bat.upload_images_rgb_batch(list(range(n_kf)), frames, "bgr", K, dist, poses)
+        for k in range(n_kf):
+            a, b = one.download_inputs(k), bat.download_inputs(k)
+            assert (a[0] == b[0]).all() and (b[0] == oracle.ingest(frames[k], "bgr", K, dist)).all()
+            assert_bit_equal(a[1], b[1])
+            assert_bit_equal(a[2], b[2])
+            assert np.float32(a[3]) == np.float32(b[3])
+            assert one.active_list(k)[1] == bat.active_list(k)[1]
+    one.close()
+    bat.close()

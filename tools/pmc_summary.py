@@ -45,8 +45,11 @@ if k1:
         ap.add_argument("--nbrs", type=int, default=20)
         ap.add_argument("--res", default="480p")
         ap.add_argument("--disparity", type=float, default=2.6)
+        ap.add_argument("--noise", action="store_true")
+        ap.add_argument("--outliers", type=int, default=0)
         a, _ = ap.parse_known_args(os.environ.get("PMC_BENCH_ARGS", "").split())
-        out["workload"] = {"res": a.res, "kfs": a.kfs, "nbrs": a.nbrs, "disparity": a.disparity}
+        out["workload"] = {"res": a.res, "kfs": a.kfs, "nbrs": a.nbrs, "disparity": a.disparity, "noise": a.noise,
+                           "outliers": a.outliers}
         out["src_hash"] = bench.source_hash()
         out["source"] = "tools/pmc.sh (rocprofv3 --pmc, one counter group per pass)"
         json.dump(out, open(root + "/traffic.json", "w"), indent=1)
