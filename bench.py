@@ -386,7 +386,7 @@ def main():
 
     wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
                   independent=args.independent, noise=args.noise, outliers=(args.outliers if world == 1 else 0),
-                  keep_images=(args.cpu_kfs + 2 * args.nbrs) if (rank == 0 and world == 1) else 0)
+                  keep_images=max(args.cpu_kfs + 2 * args.nbrs, min(args.kfs, 64)) if (rank == 0 and world == 1) else 0)
     eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
     n_total = wl.n_total * (world if args.independent else 1)
     arch = eng.arch()
@@ -445,7 +445,8 @@ def main():
         slots = [pl["slot"][k] for k in ks]
         ims = [wl.images[k] for k in ks]
         poses = [wl.scene.Tcw(k) for k in ks]
-        pinned = [eng.host_alloc((H, W)) for _ in ks]
+        block = eng.host_alloc((len(ks), H, W))  # a frame queue in pinned memory: one block, frames back to back
+        pinned = [block[i] for i in range(len(ks))]
         for a, im in zip(pinned, ims):
             a[...] = im
 
@@ -470,8 +471,7 @@ def main():
             "per_keyframe_calls": timed_upload(single, reps=1) * 1e3,
             "keyframes": len(ks),
         }
-        for a in pinned:
-            eng.host_free(a)
+        eng.host_free(block)
 
     stats = None if args.no_stats else wl.scan_stats()  # untimed counting variant of K1
 

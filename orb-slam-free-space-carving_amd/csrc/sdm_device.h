@@ -376,6 +376,9 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 8  (lost: +3 %, tools/experiments/k1_lds_constants.patch) per-pair constants read from an LDS copy into vector registers
 // bit 9  GetFusion's 1/sigma^2 (double) from a float seed and three FMA steps instead of the IEEE double division
 // bits 10, 11 (lost: +2 % / neutral) one exec-mask region per candidate; gate 2's |.| as an AND with a literal
+// bit 12 (lost: +1.2 %, EXPERIMENTS.md) wave-uniform scan plan: the wave's longest range is covered by batches of 4 and 3
+//        records (exact for every length >= 6) instead of by batches of 4 until the last lane is done -- a padding slot only
+//        costs ~13 vector instructions (the wave branches past the gates), less than the plan's wave-wide maximum
 #ifndef SDM_K1_OPT
 #define SDM_K1_OPT 0x27f
 #endif
@@ -485,100 +488,142 @@ struct ScanState {
 };
 
 // PM.cc:405-443: the scan over uj = lo..hi of one search.  Candidates are visited in increasing uj exactly as the
-// reference does (the strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched four at a
-// time so that four independent 16-byte gathers are in flight per lane.  Fetch rows are clamped into [1, H-2]
-// (validity is decided separately from the unclamped value); fetch columns run to hi+3 <= W+2 at most, and
-// (H-2)*W + W+2 < H*W, so every address stays inside the neighbour's plane without a column clamp.
+// reference does (the strict '<' at PM.cc:437 makes the lowest uj win ties), but their records are fetched NB at a
+// time so that NB independent 16-byte gathers are in flight per lane.  Fetch rows are clamped into [1, H-2]
+// (validity is decided separately from the unclamped value); fetch columns run to hi+3 <= W+2 at most (a lane only
+// enters a batch while u0 <= hi), and (H-2)*W + W+2 < H*W, so every address stays inside the neighbour's plane without
+// a column clamp.
 // CLEAN: every angle is in [0,360] (PairConst::clean), so d2, d3 are in [-360,360] and the closed-form gates hold for
 // every candidate; otherwise a candidate with d >= gate_lim (or NaN) takes the reference statement.
-template <bool STATS, bool CLEAN>
-__device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int W, int H, int lo, int hi, float ab,
-                                             float cb, float pixel, float grad1, float th_line, float ang_pi_rot,
-                                             float gate_lim, const DevParams& prm, ScanState& S, SearchStats* st)
+struct ScanConst {
+    const char* nbase;
+    unsigned W16;  // record pitch in bytes (< 2^24)
+    float hlim_b;  // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged
+                   // (and its integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3
+    float ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim;
+    int hi;
+};
+template <bool STATS, bool CLEAN, int NB>
+__device__ __forceinline__ void scan_batch(const ScanConst& q, int u0, float u0f, const DevParams& prm, ScanState& S,
+                                           SearchStats* st)
 {
-    // largest float below H-1: clamping yf to [1, hlim_b] leaves exactly the valid rows 1 <= yf < H-1 unchanged (and its
-    // integer part is at most H-2), so "clamped == original" is the row test of PM.cc:408 + N3 in one comparison
-    const float hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
-    const unsigned W16 = (unsigned)W << 4;  // record pitch in bytes (< 2^24)
+    float yfs[NB];
+    unsigned long long rowok[NB];  // lane masks taken before the loads: scalar registers, not VGPRs
+    v4f rs[NB];
+    const unsigned c0 = (unsigned)u0 << 4;
 #if !(SDM_K1_OPT & 0x01)
-    const unsigned hi16 = (unsigned)max(hi, 0) << 4;
+    const unsigned hi16 = (unsigned)max(q.hi, 0) << 4;
 #endif
-    float u0f = (float)lo;                  // (float)uj without a conversion per candidate: exact below 2^24
-    for (int u0 = lo; u0 <= hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL) {
-        float yfs[SCAN_UNROLL];
-        unsigned long long rowok[SCAN_UNROLL];  // lane masks taken before the loads: scalar registers, not VGPRs
-        v4f rs[SCAN_UNROLL];
-        const unsigned c0 = (unsigned)u0 << 4;
 #pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++) {
-            float yf = -(ab * (u0f + (float)k) + cb);  // PM.cc:407,433
-            float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, hlim_b);
+    for (int k = 0; k < NB; k++) {
+        float yf = -(q.ab * (u0f + (float)k) + q.cb);  // PM.cc:407,433
+        float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, q.hlim_b);
 #if SDM_K1_OPT & 0x01
-            const unsigned off = __umul24((unsigned)(int)yc, W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
-            const char* __restrict__ nb_k = nbase + 16 * k;
+        const unsigned off = __umul24((unsigned)(int)yc, q.W16) + c0;  // one v_mad_u32_u24; 16*k rides in the instruction
+        const char* __restrict__ nb_k = q.nbase + 16 * k;
 #else
-            unsigned uc16 = min(c0 + 16u * k, hi16);                    // min(uj, hi) * 16
-            unsigned off = __umul24((unsigned)(int)yc, W16) + uc16;     // one v_mad_u32_u24
-            const char* __restrict__ nb_k = nbase;
+        unsigned uc16 = min(c0 + 16u * k, hi16);                    // min(uj, hi) * 16
+        unsigned off = __umul24((unsigned)(int)yc, q.W16) + uc16;     // one v_mad_u32_u24
+        const char* __restrict__ nb_k = q.nbase;
 #endif
-            yfs[k] = yf;
-            rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
+        yfs[k] = yf;
+        rowok[k] = __builtin_amdgcn_fcmpf(yc, yf, 1 /* ordered == */);
 #if SDM_ABLATE == 5
-            rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
+        rs[k] = v4f{20.0f + (float)(off & 15u), 10.0f, 21.0f, __uint_as_float(0x6040u)};
 #else
-            rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
+        rs[k] = *reinterpret_cast<const v4f*>(nb_k + off);
 #endif
-        }
-        // keep each record one 16-byte gather issued here: without this hipcc splits the first record
-        // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
+    }
+    // keep each record one 16-byte gather issued here: without this hipcc splits the first record
+    // into a 4-byte load plus a dependent 12-byte load behind the gradient gate (a second round trip)
 #pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++)
-            asm volatile("" : "+v"(rs[k]));
+    for (int k = 0; k < NB; k++)
+        asm volatile("" : "+v"(rs[k]));
 #pragma unroll
-        for (int k = 0; k < SCAN_UNROLL; k++) {
-            const int uj = u0 + k;
-            if (STATS && uj <= hi) st->candidates++;
-            const float yf = yfs[k];
-            const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
-            if (!((uj <= hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
-            if (r.x < prm.lambdaG) continue;                            // PM.cc:411
+    for (int k = 0; k < NB; k++) {
+        const int uj = u0 + k;
+        if (STATS && uj <= q.hi) st->candidates++;
+        const float yf = yfs[k];
+        const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
+        if (!((uj <= q.hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
+        if (r.x < prm.lambdaG) continue;                            // PM.cc:411
 #if SDM_ABLATE == 4
-            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-            continue;
+        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+        continue;
 #endif
-            const float d2 = r.y - th_line;     // PM.cc:415-416
-            const float d3 = r.y - ang_pi_rot;  // PM.cc:427
+        const float d2 = r.y - q.th_line;     // PM.cc:415-416
+        const float d3 = r.y - q.ang_pi_rot;  // PM.cc:427
 #if SDM_K1_OPT & 0x04
-            bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
+        bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
 #else
-            bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+        bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
 #endif
-            if (!CLEAN) {
-                if (__builtin_expect(!((d2 < gate_lim) & (d3 < gate_lim)), 0))
-                    fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
-            }
-            if (fail) continue;  // PM.cc:421,431
-            if (STATS) st->gate_pass++;
+        if (!CLEAN) {
+            if (__builtin_expect(!((d2 < q.gate_lim) & (d3 < q.gate_lim)), 0))
+                fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
+        }
+        if (fail) continue;  // PM.cc:421,431
+        if (STATS) st->gate_pass++;
 #if SDM_ABLATE == 3 || SDM_ABLATE == 4
-            if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-            continue;
+        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+        continue;
 #endif
-            const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
-            float pe = pixel - rec_lerp_im_w(r, y0w);          // PM.cc:433
-            float ge = grad1 - rec_lerp_grad_w(r, y0w);        // PM.cc:434
+        const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
+        float pe = q.pixel - rec_lerp_im_w(r, y0w);        // PM.cc:433
+        float ge = q.grad1 - rec_lerp_grad_w(r, y0w);      // PM.cc:434
 #if SDM_K1_OPT & 0x08
-            float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
+        float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
 #else
-            float err = match_cost(pe * pe, ge * ge, prm);
+        float err = match_cost(pe * pe, ge * ge, prm);
 #endif
-            if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
-                S.best_pixel = uj;
-                S.old_err = err;
-                S.best_pe = pe;
-                S.best_ge = ge;
-            }
+        if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
+            S.best_pixel = uj;
+            S.old_err = err;
+            S.best_pe = pe;
+            S.best_ge = ge;
         }
     }
+}
+
+// every lane walks its own range in batches of SCAN_UNROLL (the wave loops until its longest lane is done)
+template <bool STATS, bool CLEAN>
+__device__ __forceinline__ void scan_segment(const ScanConst& q, int lo, const DevParams& prm, ScanState& S, SearchStats* st)
+{
+    float u0f = (float)lo;  // (float)uj without a conversion per candidate: exact below 2^24
+    for (int u0 = lo; u0 <= q.hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL)
+        scan_batch<STATS, CLEAN, SCAN_UNROLL>(q, u0, u0f, prm, S, st);
+}
+
+// Wave-uniform plan (K1: all 64 lanes of the wave are here together): the wave's LONGEST range, Lmax candidates, is covered
+// by n4 batches of four and n3 batches of three records -- exactly for every Lmax >= 6 and Lmax = 3, 4, with one padding
+// slot at Lmax = 5 and up to two below 3 -- where the loop above pads every search to a multiple of four (16 % of the
+// scanned slots on the App. D scene).  A lane enters a batch while its own range lasts; the order of the candidates,
+// hence the arg-min, is the reference's.  The trip counts live in scalar registers.
+__device__ __forceinline__ int wave_max_nonneg(int v)
+{
+    // row_shr 1, 2, 4, 8, then row_bcast:15 / :31: lane 63 ends up with the maximum.  Lanes without a source read 0.
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <bool STATS, bool CLEAN>
+__device__ __forceinline__ void scan_planned(const ScanConst& q, int lo, int Lmax, const DevParams& prm, ScanState& S,
+                                             SearchStats* st)
+{
+    int n3 = (-Lmax) & 3;
+    if (Lmax <= 3) n3 = 1;
+    if (Lmax == 5) n3 = 2;
+    const int n4 = max(Lmax - 3 * n3, 0) >> 2;
+    int u0 = lo;
+    float u0f = (float)lo;
+    for (int i = 0; i < n4; i++, u0 += 4, u0f += 4.0f)
+        if (u0 <= q.hi) scan_batch<STATS, CLEAN, 4>(q, u0, u0f, prm, S, st);
+    for (int i = 0; i < n3; i++, u0 += 3, u0f += 3.0f)
+        if (u0 <= q.hi) scan_batch<STATS, CLEAN, 3>(q, u0, u0f, prm, S, st);
 }
 
 // EpipolarSearch PM.cc:385-465 with ComputeInvDepthHypothesis PM.cc:806-829.
@@ -586,10 +631,12 @@ __device__ __forceinline__ void scan_segment(const char* __restrict__ nbase, int
 // (dh.supported).  Normative choices N3-N5 for the reference's undefined behaviour: DESIGN.md §3.
 // cv: the pair's constants (layout CV_*); rcv: {fx, cx, min_depth, max_depth} of the reference keyframe;
 // clean: PairConst::clean (wave-uniform).
-template <bool STATS>
+// PLAN: the wave-uniform scan plan (scan_planned) -- every lane of the wave must make this call together, lanes without a
+// pixel with on = false.  Without it (per-pixel entry points) `on` must be true.
+template <bool STATS, bool PLAN = false>
 __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
                                                 const float* __restrict__ cv, const float* __restrict__ rcv, int clean,
-                                                int x, int y, float pixel, float grad1,
+                                                bool on, int x, int y, float pixel, float grad1,
                                                 float th_pi, float xp0, float xp1, const DevParams& prm, float& rho_o,
                                                 float& sigma_o, float& best_u, float& best_v,
                                                 SearchStats* st)
@@ -600,13 +647,16 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     sigma_o = 0.f;
     best_u = 0.f;
     best_v = 0.f;
-    if (STATS) st->searches++;
+    if (STATS && on) st->searches++;
     const float* F = cv;
     float a = (float)x * F[0] + (float)y * F[3] + F[6];  // PM.cc:389-391
     float b = (float)x * F[1] + (float)y * F[4] + F[7];
     float c = (float)x * F[2] + (float)y * F[5] + F[8];
     float ab = a / b;
-    if (!(ab >= -4 && ab <= 4)) return false;  // PM.cc:393; a NaN line yields no hypothesis
+    // PM.cc:393; a NaN line yields no hypothesis.  With PLAN the lanes stay together up to the scan (a lane that is out
+    // gets an empty range) so that the wave-wide maximum below sees all of them
+    bool live = on & (ab >= -4) & (ab <= 4);
+    if (!PLAN && !live) return false;
     float cb = c / b;
 
     float rxxp = row_dot_xp(cv + CV_RX, xp0, xp1);
@@ -614,11 +664,12 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float tx = cv[CV_TX], tz = cv[CV_TZ];
     int lo, hi;
 #if SDM_K1_OPT & 0x20
-    if (!search_range_int1(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
+    live &= search_range_int1(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi);  // PM.cc:404; N5
 #else
-    if (!search_range_int(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi)) return false;  // PM.cc:404; N5
+    live &= search_range_int(fx, cx, rxxp, rzxp, tx, tz, mind, maxd, W, lo, hi);  // PM.cc:404; N5
     if (hi > W - 1) hi = W - 1;
 #endif
+    if (!PLAN && !live) return false;
 
     // PM.cc:414 cv::fastAtan2(-a/b, 1): (-a)/b == -(a/b) exactly in IEEE arithmetic; loop invariant
     float th_line = fast_atan2_deg_x1(-ab);
@@ -631,22 +682,48 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     const float hlim2 = (float)(H - 2);
     const char* __restrict__ nbase = reinterpret_cast<const char*>(nrec);
 #if SDM_ABLATE == 10
-    if (ang_pi_rot + th_line + (float)(hi - lo) != 12345.678f) return false;  // keep the set-up alive, skip the rest
+    if (ang_pi_rot + th_line + (float)(hi - lo) != 12345.678f) live = false;  // keep the set-up alive, skip the rest
 #endif
 #if SDM_ABLATE == 11
-    if (ab + cb + rxxp + rzxp != 12345.678f) return false;  // only a,b,c, the two line quotients and the ray dot products
+    if (ab + cb + rxxp + rzxp != 12345.678f) live = false;  // only a,b,c, the two line quotients and the ray dot products
 #endif
 #if SDM_ABLATE == 6
     hi = lo - 1;
     S.old_err = ab;
     S.best_pixel = lo + 2;
 #endif
+    if (PLAN && !live) hi = lo - 1;  // an empty range: the lane enters no batch
+    ScanConst sc;
+    sc.nbase = nbase;
+    sc.W16 = (unsigned)W << 4;
+    sc.hlim_b = __uint_as_float(__float_as_uint((float)(H - 1)) - 1u);
+    sc.ab = ab;
+    sc.cb = cb;
+    sc.pixel = pixel;
+    sc.grad1 = grad1;
+    sc.th_line = th_line;
+    sc.ang_pi_rot = ang_pi_rot;
+    sc.gate_lim = gate_lim;
+    sc.hi = hi;
+    if (PLAN) {
+        const int Lmax = wave_max_nonneg(max(hi - lo + 1, 0));  // wave-uniform (a scalar register)
+        if (Lmax > 0) {
 #if SDM_K1_OPT & 0x02
-    if (clean && prm.default_gates)  // wave-uniform
-        scan_segment<STATS, true>(nbase, W, H, lo, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim, prm, S, st);
-    else
+            if (clean && prm.default_gates)  // wave-uniform
+                scan_planned<STATS, true>(sc, lo, Lmax, prm, S, st);
+            else
 #endif
-        scan_segment<STATS, false>(nbase, W, H, lo, hi, ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim, prm, S, st);
+                scan_planned<STATS, false>(sc, lo, Lmax, prm, S, st);
+        }
+        if (!live) return false;
+    } else {
+#if SDM_K1_OPT & 0x02
+        if (clean && prm.default_gates)  // wave-uniform
+            scan_segment<STATS, true>(sc, lo, prm, S, st);
+        else
+#endif
+            scan_segment<STATS, false>(sc, lo, prm, S, st);
+    }
     const float old_err = S.old_err, best_pe = S.best_pe, best_ge = S.best_ge;
     const int best_pixel = S.best_pixel;
     if (!(old_err < 1000000.0f)) return false;  // PM.cc:446

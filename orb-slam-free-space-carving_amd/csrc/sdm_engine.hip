@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +73,8 @@ struct sdm_ctx {
     float2* d_open_hyp = nullptr;
     unsigned open_capacity = 0;
     unsigned open_quota = 512;
+    unsigned open_inplace_min = 40;
+    unsigned open_grid = 2048;  // workgroups of k_fuse_open (grid-stride over the list's blocks): 8 per CU
     unsigned open_launch = 0;
     // K3's candidate list on pipeline maps (listed pixels with rho < 1e-6 and a non-zero sigma; normally empty)
     unsigned* d_grow_ctr = nullptr;  // two counters, used alternately by successive K2 launches
@@ -357,16 +360,19 @@ size_t select_set(sdm_ctx* c, int si, int n_ref, size_t np)
     return words;
 }
 
-// One dispatch stays below 2^30 work-items.  A launch of 2^31 or more (still below HIP's documented 2^32 limit) runs, but
-// not over the whole grid on this stack: K1 over 2048 keyframes of 1920x1080 in ONE launch (14.8 M workgroups x 256 =
-// 3.8e9 work-items) returned wrong maps for keyframe 0 while 1024 keyframes (1.9e9) were right (round 3,
-// tests/test_gpu_fullsize.py::test_config4_full_2048kf_1080p).  Every launch whose grid grows with the number of
-// reference keyframes is therefore issued in slices of reference keyframes: fn(first, count) launches one slice.
+// One dispatch stays at or below 2^31 work-items, half of HIP's documented limit of 2^32 - 1.  The limit is NOT enforced by
+// the runtime on this stack (ROCm 7.2, HIP 7.2.26015): a launch whose gridDim.x * blockDim.x exceeds 2^32 returns hipSuccess
+// and executes the grid MODULO 2^32 work-items (tools/ubench/big_grid.hip; profiles/r04_big_grid.txt).  That is what round 3
+// ran into: K1 over 2048 keyframes of 1920x1080 in one launch is 2048 x 9880 workgroups x 256 = 5.18e9 work-items (the
+// pixel lists grow along the sequence: 405 k entries at keyframe 0, 632 k at keyframe 2047), of which the first 0.89e9 ran
+// -- every keyframe's list positions below 108 032 -- and the rest of every map kept what it held before
+// (tools/debug/unsliced_holes.py).  Every launch whose grid grows with the number of reference keyframes is therefore issued
+// in slices of reference keyframes: fn(first, count) launches one slice.
+// (SDM_MAX_DISPATCH_LOG2: debugging knob, read per call -- how the finding was reproduced.)
 template <typename F>
 void for_ref_slices(int n_ref, long long blocks_per_ref, int threads, F&& fn)
 {
-    // (SDM_MAX_DISPATCH_LOG2: debugging knob, read per call -- tools/debug/unsliced_vs_sliced.py)
-    int lg = 30;
+    int lg = 31;
     if (const char* e = getenv("SDM_MAX_DISPATCH_LOG2")) lg = std::max(20, std::min(40, atoi(e)));
     const long long max_blocks = (1ll << lg) / threads;
     const int per = (int)std::max<long long>(1, std::min<long long>(n_ref, max_blocks / std::max<long long>(blocks_per_ref, 1)));
@@ -687,6 +693,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         long long cap = std::min<long long>(1ll << 20, std::max<long long>(K1_PX, c->P * K / 4));
         if (const char* e = getenv("SDM_K4_PAD")) c->k4_lds_pad = (unsigned)atoi(e);
         if (const char* e = getenv("SDM_OPEN_QUOTA")) c->open_quota = (unsigned)atoll(e);  // tests: 0 defers every open pixel
+        if (const char* e = getenv("SDM_OPEN_INPLACE")) c->open_inplace_min = (unsigned)atoll(e);  // tests / A-B: 65 = never
+        if (const char* e = getenv("SDM_OPEN_GRID")) c->open_grid = (unsigned)std::max(1ll, atoll(e));
         if (const char* e = getenv("SDM_OPEN_CAPACITY"))  // tests: a tiny list forces the in-place fallback
             cap = std::max<long long>(K1_PX, std::min<long long>(cap, atoll(e)));
         c->open_capacity = (unsigned)(cap / K1_PX * K1_PX);
@@ -899,24 +907,61 @@ bool host_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-// `m` images of `bytes` each into consecutive slots of a pinned block; a few helper threads when it is worth their start-up
-void stage_copy(uint8_t* dst, const uint8_t* const* src, int m, size_t bytes)
-{
-    const size_t total = (size_t)m * bytes;
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nt = (total >= ((size_t)2 << 20) && hw >= 4) ? std::min(std::min(m, 4), hw / 2) : 1;
-    auto work = [&](int t) {
-        for (int i = t; i < m; i += nt) memcpy(dst + (size_t)i * bytes, src[i], bytes);
+// Staging copies of pageable images into the pinned ring, chunk after chunk, shared between the calling thread and a few
+// helper threads that live for ONE batch call (started only when the batch is worth their start-up): chunk k's plan is
+// posted once its ring half is free, every thread copies the images i = t (mod nt) of it, the caller waits for the helpers
+// of that chunk and queues its H2D copy while they wait for the next plan.
+struct Stager {
+    struct Plan {
+        uint8_t* dst = nullptr;
+        const uint8_t* const* src = nullptr;
+        int m = 0;
+        size_t bytes = 0;
     };
-    if (nt <= 1) {
-        work(0);
-        return;
-    }
+    int nt = 1;
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-}
+    std::vector<Plan> plans;
+    std::vector<std::atomic<int> > done;
+    std::atomic<int> posted{0};
+    std::atomic<int> quit{0};
+
+    Stager(int threads, int chunks) : nt(std::max(1, threads)), plans((size_t)chunks), done((size_t)chunks)
+    {
+        for (auto& d : done) d.store(0);
+        for (int t = 1; t < nt; t++)
+            th.emplace_back([this, t] {
+                for (size_t k = 0; k < plans.size(); k++) {
+                    while (posted.load(std::memory_order_acquire) <= (int)k) {
+                        if (quit.load(std::memory_order_acquire)) return;
+                        std::this_thread::yield();
+                    }
+                    share(plans[k], t);
+                    done[k].fetch_add(1, std::memory_order_release);
+                }
+            });
+    }
+    void share(const Plan& p, int t) const
+    {
+        for (int i = t; i < p.m; i += nt) memcpy(p.dst + (size_t)i * p.bytes, p.src[i], p.bytes);
+    }
+    // chunk k (chunks are staged in order): returns when all of it is in the ring
+    void stage(int k, uint8_t* dst, const uint8_t* const* src, int m, size_t bytes)
+    {
+        plans[(size_t)k].dst = dst;
+        plans[(size_t)k].src = src;
+        plans[(size_t)k].m = m;
+        plans[(size_t)k].bytes = bytes;
+        posted.store(k + 1, std::memory_order_release);
+        share(plans[(size_t)k], 0);
+        while (done[(size_t)k].load(std::memory_order_acquire) < nt - 1) std::this_thread::yield();
+    }
+    ~Stager()
+    {
+        quit.store(1, std::memory_order_release);
+        posted.store((int)plans.size(), std::memory_order_release);  // chunks never staged (pinned sources, errors): empty plans
+        for (auto& x : th) x.join();
+    }
+};
 
 int check_batch_slots(sdm_ctx* c, int n, const int* slots)
 {
@@ -958,10 +1003,23 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (q && (rc = ensure_src_buffers(c))) return rc;
     const size_t bytes = (size_t)c->P * (q ? q->channels : 1);
-    const int cap = q ? (int)std::max<size_t>(1, std::min<size_t>((size_t)c->ing_cap, c->src_bytes / bytes)) : c->ing_cap;
+    int cap = q ? (int)std::max<size_t>(1, std::min<size_t>((size_t)c->ing_cap, c->src_bytes / bytes)) : c->ing_cap;
+    // a batch goes through in (at least) four chunks, so that the host's staging copy and the H2D copy of one chunk run
+    // while the device works on the previous one
+    cap = std::max(1, std::min(cap, std::max(4, (n + 3) / 4)));
     bool direct = false;  // some H2D copy reads the caller's (pinned) memory
     int last = -1;
-    for (int i0 = 0; i0 < n; i0 += cap) {
+    // pageable sources are staged by this thread and, for batches of 2 MB and more, up to three helpers
+    std::vector<char> pinned((size_t)n, 0);
+    size_t pageable_bytes = 0;
+    for (int i = 0; i < n && !on_device; i++) {
+        pinned[i] = host_pinned(images[i]) ? 1 : 0;
+        if (!pinned[i]) pageable_bytes += bytes;
+    }
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int n_chunks = (n + cap - 1) / cap;
+    Stager stager((pageable_bytes >= ((size_t)2 << 20) && hw >= 4) ? std::min(4, hw / 2) : 1, n_chunks);
+    for (int i0 = 0, chunk = 0; i0 < n; i0 += cap, chunk++) {
         const int m = std::min(cap, n - i0);
         const int b = c->ing_next;
         c->ing_next ^= 1;
@@ -980,13 +1038,19 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
         }
         if (!on_device) {
             int n_pinned = 0;
-            for (int i = 0; i < m; i++) n_pinned += host_pinned(images[i0 + i]) ? 1 : 0;
+            for (int i = 0; i < m; i++) n_pinned += pinned[i0 + i];
             if (n_pinned == m) {
-                for (int i = 0; i < m; i++)
-                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], bytes, hipMemcpyHostToDevice, c->up_stream));
+                // images that lie back to back in the caller's pinned block (a frame queue) travel as one copy
+                for (int i = 0; i < m;) {
+                    int r = 1;
+                    while (i + r < m && images[i0 + i + r] == images[i0 + i + r - 1] + bytes) r++;
+                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], (size_t)r * bytes, hipMemcpyHostToDevice,
+                                           c->up_stream));
+                    i += r;
+                }
                 direct = true;
             } else {
-                stage_copy(h_dst, images + i0, m, bytes);
+                stager.stage(chunk, h_dst, images + i0, m, bytes);
                 HIP_TRY(hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, c->up_stream));
             }
         }
@@ -1138,6 +1202,7 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     ol.next = c->d_open_ctr + 4 * ((c->open_launch + 1u) & 1u);
     ol.capacity = c->open_capacity;
     ol.quota = c->open_quota;
+    ol.inplace_min = c->open_inplace_min;
     ol.pix = c->d_open_pix;
     ol.vm = c->d_open_vm;
     ol.hyp = c->d_open_hyp;
@@ -1145,7 +1210,7 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     // the pixels the fusion bounds left open, 64 per workgroup; the list length stays on the device (a fixed grid walks
     // whatever is there, nothing when the list is empty)
     const size_t lds_open = (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * n + sizeof(unsigned) * (size_t)K1_PX * ((n + 3) / 4);
-    const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, 512u);
+    const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, c->open_grid);
     // (the slices of one call append to the same open list; k_fuse_open runs once behind the last one)
     for_ref_slices(n_ref, blocks_per_ref, K1_BLOCK, [&](int first, int count) {
         if (c->stats_on)
@@ -1442,15 +1507,16 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
             bool fuse = want_xyz && c->xyz != nullptr;
             for (int r = 0; r < n_ref && fuse; r++) fuse = c->xyz_sparse[ref_slots[r]] != 0;
             if (max_chunks > 0) {
+                max_chunks = (max_chunks * BLOCK + K4_BLOCK - 1) / K4_BLOCK;  // in units of the list kernel's workgroup
                 const int per_ref = 8 * ((max_chunks + 7) / 8);
-                for_ref_slices(n_ref, per_ref, BLOCK, [&](int first, int count) {
+                for_ref_slices(n_ref, per_ref, K4_BLOCK, [&](int first, int count) {
                     const dim3 grid(per_ref * count);
                     if (fuse)
-                        hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
+                        hipLaunchKernelGGL(k_inter_check_list<true>, grid, dim3(K4_BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
                                            c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
                                            c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
                     else
-                        hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
+                        hipLaunchKernelGGL(k_inter_check_list<false>, grid, dim3(K4_BLOCK), c->k4_lds_pad, c->stream, c->pool, c->P,
                                            c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks,
                                            c->dprm.lambdaN, c->d_act, c->chk, c->d_meta, c->xyz);
                 });

@@ -203,6 +203,9 @@ struct OpenList {
                               // they count in place.  A launch with only a handful of open pixels (clean data) then leaves the list
                               // empty and k_fuse_open returns at once -- a non-empty list costs its launch ~15 us of
                               // latency (one workgroup's serial pair loop), however short it is.
+    unsigned inplace_min;     // a workgroup with at least this many open pixels (of 64) counts in place as well: its pair loop
+                              // runs with most lanes busy, so handing the pixels over would only add the list traffic
+                              // (data on which nothing fuses cleanly -- i.i.d.-noise images -- has all 64 open)
     long long* pix;           // [capacity] element index into the depth pool
     unsigned long long* vm;   // [capacity] accepted-hypothesis mask
     float2* hyp;              // [capacity/64][n][64] {rho, sigma}
@@ -336,16 +339,29 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         const PairConst* __restrict__ pc = pcs + j;
         const float4* __restrict__ nrec = rec + (long long)pc->nbr_slot * plane;
         float2 h = make_float2(__builtin_inff(), 1.0f);
+#if SDM_K1_OPT & 0x1000
+        {  // all 64 lanes together (wave-uniform scan plan); lanes past the end of the list search nothing
+            float rho, sigma, bu, bv;
+            const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
+            bool ok = epipolar_search<STATS, true>(nrec, W, H, cv, rcv, pc->clean, on, x, y, pixel, grad1, th_pi, xp0, xp1, prm,
+                                                   rho, sigma, bu, bv, &st);
+            if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
+                h = make_float2(rho, sigma);
+                mymask |= 1ull << j;
+            }
+        }
+#else
         if (on) {
             float rho, sigma, bu, bv;
             const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
-            bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
+            bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, true, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
                                              sigma, bu, bv, &st);
             if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
                 h = make_float2(rho, sigma);
                 mymask |= 1ull << j;
             }
         }
+#endif
         hyp[j * K1_PX + p] = make_float2(h.x, safe_rcp_sq(h.y));
         sgm[j * K1_PX + p] = h.y;
     }
@@ -462,7 +478,9 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         if (tid == 0) {
             const unsigned cntw = (unsigned)__popcll(open_mask);
             unsigned first = 0xFFFFFFFFu;  // count in place
-            if (atomicAdd(&open_list.count[0], cntw) >= open_list.quota) {
+            // (a dense workgroup touches no counter at all: on data where every workgroup is dense, 300 k workgroups adding to
+            // the same three words cost more than their pair loops)
+            if (cntw < open_list.inplace_min && atomicAdd(&open_list.count[0], cntw) >= open_list.quota) {
                 const unsigned base = atomicAdd(&open_list.count[2], cntw);  // entries base .. base+cntw-1 of the list
                 if (base <= open_list.capacity && cntw <= open_list.capacity - base)
                     first = base;
@@ -1047,13 +1065,22 @@ __device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ 
     return K4Sums{kf_count, sum_Jr, sum_JJ};
 }
 
-// the straight-line form for one neighbour; *slow is set for lanes whose result must not be used
-__device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict__ nb, const PairConst* __restrict__ pc,
-                                                       int W, float colsm1, float rowsm1, float xp0, float xp1,
-                                                       float depthp, float dp, const K4Guard& g0, K4Sums in,
-                                                       bool* slow)
+// the straight-line form for one neighbour, in three steps so that the caller can have the NEXT neighbour's rows in flight
+// while this one's taps are evaluated (SDM_K4_PIPE): projection -> row fetch -> taps; *slow is set for lanes whose result
+// must not be used
+struct K4Proj {
+    unsigned off;  // byte offset of pixel (y0, x0) inside the neighbour's map (0 when the projection falls outside)
+    bool valid;
+    float depthj, rzxp;
+    K4Guard g;
+};
+struct K4Rows {
+    Row2 ra, rb;  // rows y0 and y0 + 1, columns x0 and x0 + 1
+};
+__device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1, float xp0,
+                                                float xp1, float depthp, float dp, const K4Guard& g0)
 {
-    const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
+    K4Proj P;
     K4Guard g = g0;
     const float n0 = row_dot_xp(pc->Rx, xp0, xp1), n1 = row_dot_xp(pc->Ry, xp0, xp1);
     const float rzxp = row_dot_xp(pc->Rz, xp0, xp1);
@@ -1069,23 +1096,39 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
     const float r2 = rcp_fast(t2);
     const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
     const float denom2 = depthp * pc->tz;
-    const float depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    P.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
     // PM.cc:695: 0 <= xj < cols-1 and 0 <= yj < rows-1 as ONE unsigned comparison per coordinate: x + 0.0f turns a -0
     // (which passes "x >= 0") into +0, a non-negative float orders like its bit pattern, negative values and NaN land
     // above every bound
     const unsigned bx = __float_as_uint(xj + 0.0f), by = __float_as_uint(yj + 0.0f);
-    const bool valid = (bx < __float_as_uint(colsm1)) & (by < __float_as_uint(rowsm1));
+    P.valid = (bx < __float_as_uint(colsm1)) & (by < __float_as_uint(rowsm1));
     // (int)xj truncates, which is floor for the valid (non-negative) coordinates; lanes that project outside fetch
     // pixel (0,0): the loads stay unconditional, their taps never count.  Byte offsets from the neighbour's plane
     // (8 bytes per pixel, < 2^30) keep the address arithmetic in 32 bits: one 24-bit multiply-add and a shift.
-    unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
-    off = valid ? off : 0u;
+    const unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
+    P.off = P.valid ? off : 0u;
+    P.rzxp = rzxp;
+    P.g = g;
+    return P;
+}
+__device__ __forceinline__ K4Rows inter_fetch(const float2* __restrict__ nb, int W, unsigned off)
+{
     const char* __restrict__ nbb = reinterpret_cast<const char*>(nb);
-    const Row2 ra = *reinterpret_cast<const Row2*>(nbb + off);
-    const Row2 rb = *reinterpret_cast<const Row2*>(nbb + (size_t)W * 8 + off);
+    K4Rows R;
+    R.ra = *reinterpret_cast<const Row2*>(nbb + off);
+    R.rb = *reinterpret_cast<const Row2*>(nbb + (size_t)W * 8 + off);
+    return R;
+}
+__device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, const K4Proj& P, const K4Rows& R, float dp,
+                                             K4Sums in, bool* slow)
+{
+    const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
+    K4Guard g = P.g;
+    const float rzxp = P.rzxp, depthj = P.depthj;
+    const Row2 ra = R.ra, rb = R.rb;
     const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
     const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
-    const float lim = valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
+    const float lim = P.valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
     float nsJr = in.sum_Jr, nsJJ = in.sum_JJ;
     float njf = 0.0f;
     unsigned amb = 0;
@@ -1136,7 +1179,19 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
             (t_hi > K4_TAP_HI) | (absbits(rzxp) >= 0x49800000u /* 2^20 */);
     return K4Sums{in.kf_count + nj, nsJr, nsJJ};  // PM.cc:755
 }
+__device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict__ nb, const PairConst* __restrict__ pc,
+                                                       int W, float colsm1, float rowsm1, float xp0, float xp1,
+                                                       float depthp, float dp, const K4Guard& g0, K4Sums in,
+                                                       bool* slow)
+{
+    const K4Proj P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+    const K4Rows R = inter_fetch(nb, W, P.off);
+    return inter_taps(pc, P, R, dp, in, slow);
+}
 
+#ifndef SDM_K4_PIPE
+#define SDM_K4_PIPE 0  // 1: the next neighbour's projection and row fetch are issued before this neighbour's taps are evaluated
+#endif
 __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ pool,
                                                    long long plane, const RefConst& rc,
                                                    const PairConst* __restrict__ pcs, int n, int W, int H, int x,
@@ -1149,6 +1204,26 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
     guard_divisor(g0, depthp);
     K4Sums acc = {0, 0.f, 0.f};
+#if SDM_K4_PIPE
+    K4Proj P = inter_project(pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+    K4Rows R = inter_fetch(pool + (long long)pcs->nbr_slot * plane, W, P.off);
+    for (int j = 0; j < n; j++) {
+        const PairConst* __restrict__ pc = pcs + j;
+        const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
+        // the next neighbour's rows are requested before this one's are consumed (the last round repeats its own: in cache)
+        const PairConst* __restrict__ pcn = pcs + min(j + 1, n - 1);
+        const K4Proj Pn = inter_project(pcn, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+        const K4Rows Rn = inter_fetch(pool + (long long)pcn->nbr_slot * plane, W, Pn.off);
+        bool slow;
+        const K4Sums fast = inter_taps(pc, P, R, dp, acc, &slow);
+        if (__builtin_expect(slow, 0))
+            acc = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, acc);
+        else
+            acc = fast;
+        P = Pn;
+        R = Rn;
+    }
+#else
     for (int j = 0; j < n; j++) {
         const PairConst* __restrict__ pc = pcs + j;
         const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
@@ -1159,6 +1234,7 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
         else
             acc = fast;
     }
+#endif
     if (acc.kf_count < lambdaN) return 0.0f;      // PM.cc:764
     float dpDelta = (-acc.sum_Jr) / acc.sum_JJ;   // PM.cc:788-791
     return rcp_exact(dp + dpDelta);               // PM.cc:793
@@ -1235,8 +1311,12 @@ __device__ __forceinline__ void pointset_pixel(const KfMeta& m, int x, int y, fl
 // checked plane is written, the rest of it must already equal rho (= 0) -- else k_rho_copy runs first.
 // XYZ: also back-project the checked value (the reference calls UpdateSemiDensePointSet right after
 // InterKeyFrameDepthChecking, PM.cc:300-306): saves the second pass over the list and the checked plane.
+#ifndef SDM_K4_BLOCK
+#define SDM_K4_BLOCK 256  // threads per workgroup of the list kernel (64 / 128 / 256: A/B of the launch granularity, EXPERIMENTS.md)
+#endif
+constexpr int K4_BLOCK = SDM_K4_BLOCK;
 template <bool XYZ>
-__global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __restrict__ pool, long long plane,
+__global__ __launch_bounds__(K4_BLOCK) void k_inter_check_list(const float2* __restrict__ pool, long long plane,
                                                             const RefConst* __restrict__ refs,
                                                             const PairConst* __restrict__ pairs, int n_ref, int n,
                                                             int W, int H, int max_chunks, int lambdaN,
@@ -1250,7 +1330,7 @@ __global__ __launch_bounds__(BLOCK) void k_inter_check_list(const float2* __rest
     const int chunk = cl * 8 + (b & 7);
     if (chunk >= max_chunks) return;
     const RefConst rc = refs[ref];
-    const int t = chunk * BLOCK + threadIdx.x;
+    const int t = chunk * K4_BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
     const unsigned xy = act[(long long)rc.slot * plane + t];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
@@ -1361,7 +1441,7 @@ __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long p
     SearchStats st = {0, 0, 0};
     const float* cv = reinterpret_cast<const float*>(pc);
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
-    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st);
+    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, true, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st);
     out[0] = rho;
     out[1] = sigma;
     out[2] = ok ? 1.f : 0.f;

@@ -290,17 +290,21 @@ def test_config4_full_2048kf_1080p(pkg, oracle, gpu_ok):
         assert not ((c > 1e-6) & ~(r > 1e-6)).any()  # the check only removes or refines support (PM.cc:762-794)
         sup += int((c > 1e-6).sum())
     assert sup > 0.03 * (n_total // 8) * W * H, "semi-dense coverage"  # 4.7 % at this resolution
+    failures = []  # all four keyframes are compared before anything is asserted: WHICH ones differ is the finding
     for k in oracle_kfs:
         kf = {}
         for j in [k] + nbrs[k]:
             g, t, s_ = oracle.gradient_prepass(ims[j])
             kf[j] = oracle.keyframe(ims[j], g, t, s_, Kc, scene.Tcw(j))
         r, s, _ = oracle.semi_dense_recon(kf[k], [kf[j] for j in nbrs[k]], None, mn, mx)
-        assert_bit_equal(k3[k][0], r, "rho kf %d" % k)
-        assert_bit_equal(k3[k][1], s, "sigma kf %d" % k)
         c = oracle.inter_check(kf[k], r, [kf[j] for j in nbrs[k]], [k3[j][0] for j in nbrs[k]], [k3[j][1] for j in nbrs[k]])
-        assert_bit_equal(eng.download_checked(k), c, "checked rho kf %d" % k)
-        assert_bit_equal(eng.download_pointset(k), oracle.pointset(kf[k], c), "xyz kf %d" % k)
+        for what, got, want in (("rho", k3[k][0], r), ("sigma", k3[k][1], s), ("checked rho", eng.download_checked(k), c),
+                                ("xyz", eng.download_pointset(k), oracle.pointset(kf[k], c))):
+            try:
+                assert_bit_equal(got, want, "%s kf %d" % (what, k))
+            except AssertionError as e:
+                failures.append(str(e))
+    assert not failures, "\n".join(failures)
     del ims, k3
     # ---- (b) the eight rank shares, one after another
     chk_all = torch.zeros((n_total, H, W), dtype=torch.float32, device="cuda")  # the shares' checked rho (17 GB)

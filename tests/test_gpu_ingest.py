@@ -153,7 +153,7 @@ def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf):
         assert ha == hb == np_list_hash(want)
         r, s = bat.download_depth(slots[k])
         assert not r.any() and not s.any(), "a new keyframe starts with zero maps"
-        assert not bat.download_checked(slots[k]).any()
+        assert not bat.download_pointset(slots[k]).any()
     # lists follow lambdaG: rebuilt in one batch from the records
     one.set_params(lambdaG=14.0)
     bat.set_params(lambdaG=14.0)

@@ -732,22 +732,28 @@ def test_table_cache_alternating_calls(pkg, oracle, gpu_ok, seq_mid):
     eng.close()
 
 
-@pytest.mark.parametrize("open_list", ["default", "defer-all", "tiny"])
+@pytest.mark.parametrize("open_list", ["default", "defer-all", "tiny", "in-place"])
 def test_search_fuse_with_outlier_hypotheses(pkg, oracle, gpu_ok, seq_mid, monkeypatch, open_list):
     """K1's fusion takes a shortcut when the FIRST accepted hypothesis is compatible with all the others (its set is
     then the first largest one, PM.cc:616), a second one when only a few hypotheses lie outside that set and none of
     them is compatible with a member or has a larger set, and hands every other pixel to the all-pairs count
     (k_fuse_open: 64 open pixels per workgroup).  Neighbours with a wrong pose produce consistent-looking but wrong
     hypotheses (outliers): placed first, in the middle and last in the neighbour order they exercise all three paths
-    next to each other, against the oracle.  The open-pixel list has three regimes, all with the same result: the first
-    512 reservations of a launch are counted in place (default: a mix here), "defer-all" hands every open pixel to
-    k_fuse_open, "tiny" gives the list one block only so that nearly every workgroup falls back to counting in place."""
+    next to each other, against the oracle.  The open-pixel list has four regimes, all with the same result: the first
+    512 reservations of a launch and workgroups with >= 40 open pixels are counted in place (default: a mix here),
+    "defer-all" hands every open pixel to k_fuse_open, "tiny" gives the list one block only so that nearly every
+    workgroup falls back to counting in place, "in-place" makes every workgroup with an open pixel count in place."""
     import sys
     if open_list == "defer-all":
         monkeypatch.setenv("SDM_OPEN_QUOTA", "0")
+        monkeypatch.setenv("SDM_OPEN_INPLACE", "65")
     if open_list == "tiny":
         monkeypatch.setenv("SDM_OPEN_QUOTA", "0")
+        monkeypatch.setenv("SDM_OPEN_INPLACE", "65")
         monkeypatch.setenv("SDM_OPEN_CAPACITY", "64")
+    if open_list == "in-place":
+        monkeypatch.setenv("SDM_OPEN_QUOTA", "0")
+        monkeypatch.setenv("SDM_OPEN_INPLACE", "1")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import np_pm
     seq, n = seq_mid, 7

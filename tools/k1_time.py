@@ -21,9 +21,10 @@ ap.add_argument("--check", action="store_true", help="compare K1 maps with the d
 ap.add_argument("--outliers", type=int, default=0,
                 help="replace this many of every keyframe's neighbours by a copy with a wrong pose (baseline stretched by "
                      "40 %%): their hypotheses are outliers, so no pixel is settled by the fusion shortcut")
+ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (nothing fuses cleanly: every pixel is open)")
 a = ap.parse_args()
 pkg = sdm_pkg.load()
-wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0)
+wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0, noise=a.noise)
 eng, pl = wl.eng, wl.pl
 if a.outliers:
     # a second engine with kfs extra slots holding wrong-pose copies; neighbour j of keyframe k at list position

@@ -41,6 +41,56 @@ __global__ __launch_bounds__(256) void k_check(const unsigned* __restrict__ hits
         }                                                                                      \
     } while (0)
 
+// Third question: the engine's K1 (256 threads, dynamic LDS, a barrier, some workgroups returning at once, ~10 us per
+// workgroup, 8 waves per SIMD) executed only part of a 12 959 744-workgroup grid (tools/debug/unsliced_bisect.py).  Which of
+// those properties does it take?  MODE bits: 1 dynamic LDS + barrier, 2 a third of the workgroups return at once,
+// 4 ~`spin` dependent FMAs per thread (a long-running dispatch).
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mark_like_k1(unsigned* __restrict__ hits,
+                                                                                                int spin, float seed)
+{
+    extern __shared__ float lds[];
+    const unsigned b = blockIdx.x;
+    if ((MODE & 2) && (b % 3u) == 2u) {
+        if (threadIdx.x == 0) hits[b] = 256u;  // counted as done
+        return;
+    }
+    float a = seed + (float)threadIdx.x;
+    if (MODE & 4)
+        for (int i = 0; i < spin; i++) a = __builtin_fmaf(a, 1.0000001f, 0.5f);
+    if (MODE & 1) {
+        lds[threadIdx.x] = a;
+        __syncthreads();
+        a += lds[(threadIdx.x + 64) & 255];
+    }
+    if (a == 12345.678f) hits[b] = 0u;  // keeps `a` alive
+    atomicAdd(&hits[b], 1u);
+}
+
+template <int MODE>
+int run_like_k1(unsigned* hits, unsigned long long* early, unsigned blocks, int spin, hipStream_t st)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipMemsetAsync(hits, 0, sizeof(unsigned) * (size_t)blocks, st));
+    CK(hipMemsetAsync(early, 0, sizeof(unsigned long long), st));
+    CK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_mark_like_k1<MODE>, dim3(blocks), dim3(256), (MODE & 1) ? 8448 : 0, st, hits, spin, 1.0f);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1, st));
+    hipLaunchKernelGGL(k_check, dim3((blocks + 255) / 256), dim3(256), 0, st, hits, blocks, early);
+    CK(hipStreamSynchronize(st));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long e = 0;
+    CK(hipMemcpy(&e, early, sizeof(e), hipMemcpyDeviceToHost));
+    printf("K1-like dispatch, mode %d, %u workgroups x 256, spin %d, %.1f ms: %llu workgroups not (fully) executed -> %s\n", MODE,
+           blocks, spin, ms, e, e == 0 ? "OK" : "MIS-EXECUTED");
+    fflush(stdout);
+    return 0;
+}
+
 int main()
 {
     const unsigned long long items[] = {1ull << 30, (1ull << 31) - 256, 1ull << 31, (1ull << 31) + 256,
@@ -115,6 +165,44 @@ int main()
                    n, rep, e, blocks, e == 0 ? "OK" : "STARTED EARLY");
             fflush(stdout);
         }
+    }
+    // ---- what the engine really launched (tools/debug/unsliced_holes.py): 2048 keyframes x 9880 workgroups = 20 234 240
+    // workgroups x 256 = 5.18e9 work-items, ABOVE HIP's 2^32 limit.  Is that refused?
+    {
+        const unsigned blocks = 20234240u;
+        unsigned *big, *big_id;  // sized for the whole grid, in case it does run in full
+        CK(hipMalloc(&big, sizeof(unsigned) * (size_t)blocks));
+        CK(hipMalloc(&big_id, sizeof(unsigned) * (size_t)blocks));
+        CK(hipMemset(big, 0, sizeof(unsigned) * (size_t)blocks));
+        CK(hipMemset(gid_bad, 0, sizeof(unsigned long long)));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_mark, dim3(blocks), dim3(256), 0, st, big, big_id, gid_bad);
+        const hipError_t le = hipGetLastError();
+        const hipError_t se = hipStreamSynchronize(st);
+        std::vector<unsigned> hb(blocks);
+        CK(hipMemcpy(hb.data(), big, sizeof(unsigned) * (size_t)blocks, hipMemcpyDeviceToHost));
+        unsigned long long done = 0, last = 0;
+        for (size_t b = 0; b < blocks; b++)
+            if (hb[b] == 256u) {
+                done++;
+                last = b;
+            }
+        printf("grid of %u workgroups x 256 = %llu work-items (> 2^32): launch returned \"%s\", sync \"%s\"; workgroups executed: %llu "
+               "(highest index %llu); 2^32-wrapped grid would be %llu workgroups\n",
+               blocks, (unsigned long long)blocks * 256ull, hipGetErrorString(le), hipGetErrorString(se), done, last,
+               ((unsigned long long)blocks * 256ull - (1ull << 32)) / 256ull);
+        fflush(stdout);
+        CK(hipFree(big));
+        CK(hipFree(big_id));
+    }
+    // ---- the engine's launch shape
+    for (unsigned blocks : {9719808u, 12959744u, 14843750u}) {
+        if (run_like_k1<0>(hits, early, blocks, 0, st)) return 1;
+        if (run_like_k1<1>(hits, early, blocks, 0, st)) return 1;
+        if (run_like_k1<3>(hits, early, blocks, 0, st)) return 1;
+        if (run_like_k1<4>(hits, early, blocks, 400, st)) return 1;
+        if (run_like_k1<7>(hits, early, blocks, 400, st)) return 1;
+        if (run_like_k1<7>(hits, early, blocks, 2000, st)) return 1;
     }
     return 0;
 }
