@@ -559,6 +559,17 @@ def main():
         out["exchange_ms_per_step"] = exchange_ms
         for other, dt2 in others.items():
             out["value_" + other] = round(P * n_total * args.steps / dt2 / 1e6, 2)
+        # which number is which: BASELINE.json words the exchange as "RCCL all-gather of per-KF depth/sigma maps", i.e. every
+        # rank's whole block = the allgather_full form; `value` is the optimised variant (only the maps another rank reads,
+        # in the compact wire format).  Both are in this line; compare like with like.
+        out["value_exchange"] = args.exchange
+        out["value_baseline_literal"] = (round(value, 2) if args.exchange == "allgather_full" else
+                                         round(P * n_total * args.steps / others["allgather_full"] / 1e6, 2))
+        out["exchange_note"] = ("value = %s exchange (%s); value_baseline_literal = value_allgather_full = the all-gather of every "
+                                "rank's whole block, BASELINE.json's literal collective.  Multi-GPU figures are unmeasured "
+                                "until a driver run on >= 2 GPUs: a failure after transfers are posted is fatal (non-zero "
+                                "exit), there is no fall-back from there" %
+                                (args.exchange, "compact wire format" if wire_entries > 0 else "whole maps"))
         out["config"]["allgather_full_pieces"] = pkg.shard.AG_PIECES if transport == "native" else 1
         out["config"]["exchange_maps_per_rank"] = {  # maps every rank RECEIVES per step
             "allgather": (world - 1) * pl["contrib_count"], "allgather_late": (world - 1) * pl["contrib_count"],

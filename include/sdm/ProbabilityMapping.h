@@ -212,6 +212,10 @@ public:
     static bool PlanBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count, int world, int rank, int covisN,
                           sdm::BlockPlan* out);
     void SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count);
+    /* diagnostic: would the device maps of these (resident) keyframes be accepted as SOURCES of the compact exchange --
+     * pipeline maps, zero outside their pixel lists?  What SemiDenseReconBlock asks about the maps it will send before it
+     * agrees on the pass's wire format (a "no" on any rank makes every rank move whole maps). */
+    bool CompactSourcesReady(const std::vector<sdm::KeyFrame*>& kfs);
 
 private:
     int SlotOf(sdm::KeyFrame* kf);   /* uploads the keyframe on first use */

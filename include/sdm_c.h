@@ -236,6 +236,13 @@ int sdm_exchange_compact(sdm_ctx *ctx, int entries_per_map);
  * keyframe differs in either (its image differs from the sender's) leaves the destination plane as it is instead of scattering onto wrong pixels, and
  * counts the event.  *count = such maps since the last call (host-blocking; 0 on a healthy job). */
 int sdm_exchange_mismatches(sdm_ctx *ctx, int *count);
+/* The compact wire format through host memory, one map per call (host-blocking): the payload the RCCL forms would send
+ * for `slot` -> out[2 * (entries_per_map + 8)] floats ({rho,sigma} of the list entries, then the header: list length
+ * and hash), and the receiving side for a payload that travelled by another route (*refused = 1: packed with another
+ * list; the slot's plane is left alone).  Same kernels and checks as sdm_exchange_* -- for transports the engine does not
+ * drive (a host framework's own, or gloo on a one-GPU box: shard.py). */
+int sdm_compact_pack_host(sdm_ctx *ctx, int slot, float *out);
+int sdm_compact_unpack_host(sdm_ctx *ctx, int slot, const float *in, int *refused);
 /* *ready = 1 iff every listed slot's map would be accepted as a compact SOURCE now (a pipeline map under the current
  * lambdaG); the query form of the check the compact sends make.  Fold it into the per-pass wire-format agreement
  * (ProbabilityMapping::SemiDenseReconBlock does): a rank that answers 0 makes all ranks use whole maps for the pass. */

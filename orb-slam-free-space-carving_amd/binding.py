@@ -94,6 +94,8 @@ SYMBOLS = [
     ("sdm_exchange_compact", C.c_int, [_ctx, C.c_int]),
     ("sdm_exchange_mismatches", C.c_int, [_ctx, _ip]),
     ("sdm_compact_sources_ready", C.c_int, [_ctx, C.c_int, _ip, _ip]),
+    ("sdm_compact_pack_host", C.c_int, [_ctx, C.c_int, _f32p]),
+    ("sdm_compact_unpack_host", C.c_int, [_ctx, C.c_int, _f32p, _ip]),
     ("sdm_active_count", C.c_int, [_ctx, C.c_int, _ip]),
     ("sdm_download_active_list", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_uint), C.c_int, _ip, C.POINTER(C.c_ulonglong)]),
     ("sdm_intra_check_maps", C.c_int, [_ctx, _f32p, _f32p, _f32p]),
@@ -236,6 +238,7 @@ class Engine:
         self._check(self.lib.sdm_upload_image(self.ctx, slot, im.ctypes.data_as(_u8p), kp, Tp))
 
     ORDER = dict(rgb=0, bgr=1, rgba=2, bgra=3, gray=4)
+    compact_entries = 0  # wire format of the exchange (exchange_compact)
 
     def upload_image_rgb(self, slot, pixels, order, K, dist, Tcw):
         """camera frame [H, W, C] (or [H, W] gray); dist = (k1, k2, p1, p2, k3) or None"""
@@ -454,6 +457,23 @@ class Engine:
     def exchange_compact(self, entries_per_map):
         """0 = whole maps cross ranks; > 0 = the {rho,sigma} of the first entries_per_map active-list entries"""
         self._check(self.lib.sdm_exchange_compact(self.ctx, int(entries_per_map)))
+        self.compact_entries = int(entries_per_map)
+
+    COMPACT_HEADER = 8  # float2 units behind the entries (csrc/sdm_comm.h XCHG_HEADER)
+
+    def compact_pack_host(self, slot):
+        """the compact wire payload of a slot's map: float32 [entries + 8, 2]"""
+        out = np.empty((self.compact_entries + self.COMPACT_HEADER, 2), np.float32)
+        self._check(self.lib.sdm_compact_pack_host(self.ctx, int(slot), out.ctypes.data_as(_f32p)))
+        return out
+
+    def compact_unpack_host(self, slot, payload):
+        """scatter a payload into the slot's map; returns True when it was refused (packed with another list)"""
+        p = np.ascontiguousarray(payload, np.float32)
+        assert p.size == 2 * (self.compact_entries + self.COMPACT_HEADER)
+        ref = C.c_int()
+        self._check(self.lib.sdm_compact_unpack_host(self.ctx, int(slot), p.ctypes.data_as(_f32p), C.byref(ref)))
+        return bool(ref.value)
 
     def exchange_mismatches(self):
         out = C.c_int()

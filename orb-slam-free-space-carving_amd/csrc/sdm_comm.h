@@ -721,6 +721,49 @@ int sdm_exchange_compact(sdm_ctx* c, int entries_per_map)
     return SDM_OK;
 }
 
+// The compact wire format through HOST memory, one map per call (host-blocking): what k_pack_lists would put on the wire for
+// `slot` -> out[2 * (entries_per_map + 8)] floats, and the receiving side for a payload that arrived by any other route
+// (*refused = 1: the list it was packed with differs from this slot's).  The same kernels and checks as the RCCL forms --
+// this is how the format crosses a process boundary on a box with one GPU (shard.py's staged transport over gloo:
+// tests/test_gpu_shard.py, bench.py's rehearsal) and how a host framework with its own transport would use it.
+int sdm_compact_pack_host(sdm_ctx* c, int slot, float* out)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!out) return fail(SDM_EINVAL, "null buffer");
+    if (c->xchg_entries <= 0) return fail(SDM_ESTATE, "sdm_exchange_compact(ctx, entries_per_map > 0) first");
+    if (!c->has_depth[slot]) return fail(SDM_ESTATE, "slot has no reconstructed depth map");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = check_compact_sources(c, 1, &slot))) return rc;
+    if ((rc = ensure_xchg_buffers(c, 1, 0))) return rc;
+    float2* buf = c->stage_buf;
+    if ((rc = list_kernel(c, true, 1, &slot, &buf, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, buf, sizeof(float2) * (size_t)xchg_stride(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+int sdm_compact_unpack_host(sdm_ctx* c, int slot, const float* in, int* refused)
+{
+    int rc = check_slot(c, slot, true);
+    if (rc) return rc;
+    if (!in || !refused) return fail(SDM_EINVAL, "null argument");
+    if (c->xchg_entries <= 0) return fail(SDM_ESTATE, "sdm_exchange_compact(ctx, entries_per_map > 0) first");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = ensure_xchg_buffers(c, 0, 1))) return rc;
+    if ((rc = prepare_compact_destinations(c, 1, &slot, c->stream))) return rc;
+    unsigned before = 0, after = 0;
+    HIP_TRY(hipMemcpyAsync(&before, c->d_xchg_mismatch, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    float2* buf = c->gather_buf;
+    HIP_TRY(hipMemcpyAsync(buf, in, sizeof(float2) * (size_t)xchg_stride(c), hipMemcpyHostToDevice, c->stream));
+    if ((rc = list_kernel(c, false, 1, &slot, &buf, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(&after, c->d_xchg_mismatch, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *refused = after != before ? 1 : 0;
+    if (!*refused) mark_received(c, slot);
+    return SDM_OK;
+}
+
 // Would these slots' maps be accepted as compact sources right now (pipeline maps under the current lambdaG: zero outside
 // their active lists)?  The query form of the check the compact sends make before anything is posted: a driver folds it
 // into its per-pass wire-format agreement, so that a rank whose send sources do not qualify (a map restored with

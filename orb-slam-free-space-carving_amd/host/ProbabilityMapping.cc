@@ -591,6 +591,23 @@ bool ProbabilityMapping::PlanBlock(const std::vector<sdm::KeyFrame*>& all, int f
     return true;
 }
 
+bool ProbabilityMapping::CompactSourcesReady(const std::vector<sdm::KeyFrame*>& kfs)
+{
+    if (!ctx_) return false;
+    std::vector<int> s;
+    for (sdm::KeyFrame* kf : kfs) {
+        auto it = slots_.find(kf);
+        if (it == slots_.end()) return false;
+        s.push_back(it->second);
+    }
+    int ready = 0;
+    if (sdm_compact_sources_ready(ctx_, (int)s.size(), s.data(), &ready) != SDM_OK) {
+        report("CompactSourcesReady");
+        return false;
+    }
+    return ready != 0;
+}
+
 void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& all, int first, int count)
 {
     const int n_all = (int)all.size();

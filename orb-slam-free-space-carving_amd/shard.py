@@ -240,6 +240,110 @@ def allgather_boundary(pool, pl, group=None):
         pool[s].copy_(gather[i])
 
 
+# ---- the compact wire format on host arrays ------------------------------------------------------------------------------
+# What crosses ranks per map with sdm_exchange_compact(entries): the {rho,sigma} of the keyframe's active-list entries in
+# list order, then a header of XCHG_HEADER float2 -- the list length and the 64-bit hash of the list as bit patterns
+# (csrc/sdm_comm.h k_pack_lists / k_unpack_lists, csrc/sdm_ingest.h list_hash_term).  The numpy statement below is the
+# format's second implementation: the CPU tests move it between processes over gloo, the GPU tests check it against the
+# engine's own packing byte for byte.
+XCHG_HEADER = 8
+
+
+def list_hash(lst):
+    """sum over the list's (y << 16 | x) of their SplitMix64 finalisation, mod 2^64"""
+    import numpy as np
+    z = np.asarray(lst, np.uint32).astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return int(z.sum(dtype=np.uint64))
+
+
+def pack_compact(depth_map, lst, entries):
+    """depth_map: float32 [H, W, 2]; lst: uint32 (y << 16 | x); returns float32 [entries + XCHG_HEADER, 2]"""
+    import numpy as np
+    lst = np.asarray(lst, np.uint32)
+    if lst.size > entries:
+        raise ValueError("list of %d entries does not fit the wire format (%d)" % (lst.size, entries))
+    out = np.zeros((entries + XCHG_HEADER, 2), np.float32)
+    out[:lst.size] = np.asarray(depth_map, np.float32)[lst >> 16, lst & 0xFFFF]
+    h = list_hash(lst)
+    out.view(np.uint32)[entries] = (lst.size, h & 0xFFFFFFFF)
+    out.view(np.uint32)[entries + 1] = (h >> 32, 0)
+    return out
+
+
+def unpack_compact(payload, lst, entries, depth_map):
+    """scatters a payload through the receiver's list into depth_map (float32 [H, W, 2], zero outside the list);
+    returns False -- and leaves the map alone -- when the payload was packed with another list"""
+    import numpy as np
+    lst = np.asarray(lst, np.uint32)
+    u = np.asarray(payload, np.float32).view(np.uint32)
+    h = list_hash(lst)
+    if (int(u[entries, 0]), int(u[entries, 1]), int(u[entries + 1, 0])) != (lst.size, h & 0xFFFFFFFF, h >> 32):
+        return False
+    depth_map[lst >> 16, lst & 0xFFFF] = np.asarray(payload, np.float32)[:lst.size]
+    return True
+
+
+class HostCompactCodec:
+    """pack / deliver on host arrays (CPU rehearsal): pool is a CPU tensor [slots, H, W, 2], lists[slot] the slot's list"""
+
+    def __init__(self, pool, lists, entries):
+        self.pool, self.lists, self.entries, self.refused = pool, lists, entries, 0
+
+    def pack(self, slot):
+        return torch.from_numpy(pack_compact(self.pool[slot].numpy(), self.lists[slot], self.entries))
+
+    def deliver(self, slot, payload):
+        if not unpack_compact(payload.numpy(), self.lists[slot], self.entries, self.pool[slot].numpy()):
+            self.refused += 1
+
+
+class EngineCompactCodec:
+    """pack / deliver through the engine's own kernels and host memory (sdm_compact_pack_host / _unpack_host)"""
+
+    def __init__(self, eng):
+        self.eng, self.entries, self.refused = eng, eng.compact_entries, 0
+
+    def pack(self, slot):
+        return torch.from_numpy(self.eng.compact_pack_host(slot))
+
+    def deliver(self, slot, payload):
+        if self.eng.compact_unpack_host(slot, payload.numpy()):
+            self.refused += 1
+
+
+def exchange_halo_compact(codec, pl, group=None):
+    """torch transport, compact payloads staged through host memory: the point-to-point form"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    slot = pl["slot"]
+    ops, recvs = [], []
+    for peer in sorted(set(pl["send"]) | set(pl["recv"])):
+        for k in pl["send"].get(peer, []):
+            ops.append(dist.P2POp(dist.isend, codec.pack(slot[k]), peer, group=group))
+        for k in pl["recv"].get(peer, []):
+            buf = torch.empty((codec.entries + XCHG_HEADER, 2), dtype=torch.float32)
+            recvs.append((slot[k], buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=group))
+    if ops:
+        wait_all(dist.batch_isend_irecv(ops))
+    for s, buf in recvs:
+        codec.deliver(s, buf)
+
+
+def allgather_boundary_compact(codec, pl, group=None):
+    """torch transport, compact payloads staged through host memory: the boundary all-gather"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    mine = torch.stack([codec.pack(s) for s in contrib_slots(pl)])
+    gather = torch.empty((pl["world"] * pl["contrib_count"],) + tuple(mine.shape[1:]), dtype=torch.float32)
+    dist.all_gather_into_tensor(gather, mine, group=group)
+    for i, s in contrib_fetch_list(pl):
+        codec.deliver(s, gather[i])
+
+
 def setup_native_comm(eng, group=None):
     """Builds the engine's RCCL communicator: rank 0 draws the unique id and the bytes travel over the
     existing torch.distributed group (any channel would do; the C++ drop-in would use a file or MPI)."""
@@ -310,8 +414,11 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
     # (the transfer has the interior keyframes' K1-K3 and their K4 to hide behind), the others after it.
     if world > 1 and exchange == "halo" and boundary:
         eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+        compact = (not native) and getattr(eng, "compact_entries", 0) > 0
         if native:
             eng.exchange_halo_begin(*halo_lists(pl))
+        elif compact:
+            works = None
         else:
             works = exchange_halo_async(pool, pl, group)
         if interior:
@@ -319,6 +426,10 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         check(early)
         if native:
             eng.exchange_wait()
+        elif compact:  # host-staged compact payloads (blocking: a rehearsal transport)
+            codec = EngineCompactCodec(eng)
+            exchange_halo_compact(codec, pl, group)
+            eng.staged_refused = getattr(eng, "staged_refused", 0) + codec.refused
         else:
             wait_all(works)
             eng.mark_depth_present([s for _, s in halo_lists(pl)[1]])
@@ -338,6 +449,13 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
                 eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
             check(early)
             eng.allgather_finish(contrib_fetch_list(pl))
+        elif getattr(eng, "compact_entries", 0) > 0:
+            codec = EngineCompactCodec(eng)
+            allgather_boundary_compact(codec, pl, group)
+            eng.staged_refused = getattr(eng, "staged_refused", 0) + codec.refused
+            if rest:
+                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+            check(early)
         else:
             allgather_boundary(pool, pl, group)
             if rest:
@@ -355,6 +473,11 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
             eng.allgather_piece(contrib_slots(pl))
             check(early)
             eng.allgather_finish(contrib_fetch_list(pl))
+        elif getattr(eng, "compact_entries", 0) > 0:
+            codec = EngineCompactCodec(eng)
+            allgather_boundary_compact(codec, pl, group)
+            eng.staged_refused = getattr(eng, "staged_refused", 0) + codec.refused
+            check(early)
         else:
             allgather_boundary(pool, pl, group)
             check(early)

@@ -75,7 +75,13 @@ int main(int argc, char** argv)
         idp = comm_id;
     }
     if (!pm.InitSharding(idp, 1, 0)) return idp ? 6 : 4;
+    // after pass 1 the device maps are still the reconstructed ones: compact sources
+    if (!pm.CompactSourcesReady(map.keyframes)) return 7;
     pm.SemiDenseReconBlock(map.keyframes, 0, n_kf);  // second pass: everything already reconstructed -> no work, no change
+    // ... and the second pass restored the (checked) host maps into the slots WITHOUT disqualifying them: a sharded second
+    // pass sends such maps, and a compact send of a map that is not a pipeline map fails on the sender alone, after its
+    // peers have posted their receives (round-3 advice)
+    if (!pm.CompactSourcesReady(map.keyframes)) return 8;
 
     // slot-cache contract
     std::vector<float> xyz1 = kfs[1].SemiDensePointSets_.data, xyz2 = kfs[2].SemiDensePointSets_.data;

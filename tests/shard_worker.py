@@ -5,7 +5,9 @@ of {rho,sigma} maps, inter-keyframe check against received maps -- runs on a one
 
 Slots are LOCAL (own block + input halo, shard.plan): the engine of a rank holds len(inputs) keyframes.
 
-usage: shard_worker.py OUT_DIR EXCHANGE N_TOTAL N_NBR"""
+usage: shard_worker.py OUT_DIR EXCHANGE N_TOTAL N_NBR [compact]
+(compact: the maps cross the process boundary in the compact wire format -- packed and scattered by the engine's own
+kernels, sdm_compact_pack_host / _unpack_host, staged through host memory; the entries per map are agreed over the group)"""
 import os
 import sys
 
@@ -42,10 +44,13 @@ def main():
         torch.cuda.synchronize()
         eng.upload_image_device(slot[k], im.data_ptr(), scene.K(), scene.Tcw(k))
     min_d, max_d = scene.depth_prior()
+    compact = len(sys.argv) > 5 and sys.argv[5] == "compact"
+    entries = pkg.shard.agree_compact_wire(eng, pl) if compact else 0
     for _ in range(2):  # twice: the second pass must not depend on state left by the first
         pkg.shard.pipeline_step(eng, pool, pl, min_d, max_d, exchange, transport="torch")
     torch.cuda.synchronize()
-    out = {"own": np.array(pl["own"]), "recv": np.array(sorted(j for v in pl["recv"].values() for j in v))}
+    out = {"entries": np.array([entries]), "refused": np.array([getattr(eng, "staged_refused", 0)]),
+           "own": np.array(pl["own"]), "recv": np.array(sorted(j for v in pl["recv"].values() for j in v))}
     for k in pl["own"]:
         r, s = eng.download_depth(slot[k])
         out["rho%d" % k], out["sig%d" % k] = r, s

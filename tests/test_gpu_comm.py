@@ -277,6 +277,33 @@ def test_compact_wire_format(pkg, oracle, gpu_ok, monkeypatch, rccl):
     eng.allgather_finish([(0, K + 2)])
     assert eng.exchange_mismatches() == 1 and eng.exchange_mismatches() == 0
     assert_bit_equal(eng.download_depth(K + 2)[0], before[0], "a refused map leaves the destination untouched")
+    # the same format through host memory (sdm_compact_pack_host / _unpack_host), against its numpy statement
+    # (shard.pack_compact / unpack_compact -- what the CPU tests move between processes): byte for byte
+    shard = pkg.shard
+    for k in (0, 5):
+        lst, h = eng.active_list(k)
+        assert h == shard.list_hash(lst)
+        payload = eng.compact_pack_host(k)
+        m = np.stack(maps[k], axis=2)
+        want = shard.pack_compact(m, lst, E)
+        assert (payload.view(np.uint32)[:lst.size] == want.view(np.uint32)[:lst.size]).all()
+        assert (payload.view(np.uint32)[E:E + 2] == want.view(np.uint32)[E:E + 2]).all(), "header: length and hash"
+        eng.upload_depth(K + k, junk, junk)
+        assert not eng.compact_unpack_host(K + k, want)  # a numpy-packed payload, scattered by the device
+        r, sg = eng.download_depth(K + k)
+        assert_bit_equal(r, maps[k][0], "host payload rho kf %d" % k)
+        assert_bit_equal(sg, maps[k][1])
+        back = np.zeros_like(m)
+        assert shard.unpack_compact(payload, lst, E, back) and (back.view(np.uint32) == m.view(np.uint32)).all()
+        # a payload packed with a list of the SAME length but another hash (one bit of the hash flipped) is refused
+        forged = payload.copy()
+        forged.view(np.uint32)[E, 1] ^= 1
+        before = eng.download_depth(K + k)
+        assert eng.compact_unpack_host(K + k, forged)
+        assert_bit_equal(eng.download_depth(K + k)[0], before[0], "a refused payload leaves the destination untouched")
+    assert eng.exchange_mismatches() == 2
+    eng.upload_depth(K + 3, junk, junk)  # an arbitrary map is no compact source; a reconstructed or compact-received one is
+    assert eng.compact_sources_ready([0, 5, K + 5]) and not eng.compact_sources_ready([0, K + 3])
     eng.exchange_compact(0)
     eng.allgather_depth(0, K, fetch=[])  # whole maps again
     eng.close()

@@ -28,6 +28,9 @@ def _free_port():
     return port
 
 
+CAMPX = shard_worker.CAM["W"] * shard_worker.CAM["H"]
+
+
 def _single_rank(pkg, n_total, n_nbr):
     cam = shard_worker.CAM
     scene = pkg.synth.Scene(cam, shard_worker.SEED)
@@ -47,14 +50,18 @@ def _single_rank(pkg, n_total, n_nbr):
     return res
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (2, "allgather_full"), (3, "halo"), (3, "allgather"), (2, "allgather_late")])
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (2, "allgather_full"), (3, "halo"), (3, "allgather"), (2, "allgather_late"),
+                                            (2, "halo+compact"), (3, "allgather+compact")])
 def test_sharded_equals_single_rank(pkg, gpu_ok, tmp_path, world, exchange):
+    """+compact: the maps cross the PROCESS boundary in the compact wire format (the engine's pack / scatter kernels on
+    both sides, gloo in between) -- the format's first trip between two processes with real device lists"""
     n_total, n_nbr = 12, 4
+    exchange, _, wire = exchange.partition("+")
     want = _single_rank(pkg, n_total, n_nbr)
     assert sum(int((c > 1e-6).sum()) for (_, c, _) in want.values()) > 1000, "the scene must produce checked depth"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "shard_worker.py"), str(tmp_path), exchange, str(n_total), str(n_nbr)]
+           os.path.join(ROOT, "tests", "shard_worker.py"), str(tmp_path), exchange, str(n_total), str(n_nbr)] + ([wire] if wire else [])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -62,6 +69,9 @@ def test_sharded_equals_single_rank(pkg, gpu_ok, tmp_path, world, exchange):
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         crossed += len(z["recv"])
+        assert int(z["refused"][0]) == 0
+        if wire:
+            assert 0 < int(z["entries"][0]) < CAMPX // 2, "the compact format was in use"
         for k in z["own"].tolist():
             (rho, sig), chk, xyz = want[k]
             assert_bit_equal(z["rho%d" % k], rho, "rho kf %d" % k)

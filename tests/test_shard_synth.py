@@ -103,12 +103,79 @@ def _worker(rank, world, port, n_total, H, W, out, mode="allgather", n_nbr=4):
     dist.destroy_process_group()
 
 
+def _kf_list(k, H, W, moved=False):
+    """a keyframe's active-pixel list as every rank that holds the keyframe's image derives it: (y << 16 | x), raster
+    order, here a deterministic pseudo-random ~25 % of the inset pixels; moved: one pixel displaced (same length)"""
+    rng = np.random.default_rng(1000 + k)
+    m = rng.random((H, W)) < 0.25
+    m[:2] = m[-2:] = False
+    m[:, :2] = m[:, -2:] = False
+    if moved:
+        ys, xs = np.nonzero(m)
+        m[ys[3], xs[3]] = False
+        ys0, xs0 = np.nonzero(~m[2:-2, 2:-2])
+        m[ys0[5] + 2, xs0[5] + 2] = True
+    ys, xs = np.nonzero(m)
+    return (ys.astype(np.uint32) << 16) | xs.astype(np.uint32)
+
+
+def _kf_map(k, lst, H, W):
+    m = np.zeros((H, W, 2), np.float32)
+    t = np.arange(lst.size, dtype=np.float32)
+    m[lst >> 16, lst & 0xFFFF, 0] = k + 0.25 + t / 4096
+    m[lst >> 16, lst & 0xFFFF, 1] = -(k + 0.5) - t / 8192
+    return m
+
+
+def _compact_worker(rank, world, port, n_total, H, W, out, mode, n_nbr):
+    """the compact wire format between PROCESSES (gloo): every rank packs the maps it owns through its own copy of the
+    keyframe's list, the receiver scatters them through ITS copy; a receiver whose list differs refuses the map"""
+    sys.path.insert(0, ROOT)
+    import sdm_pkg
+    pkg = sdm_pkg.load()
+    shard = pkg.shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pl = shard.plan(n_total, world, rank, n_nbr, pkg.synth.Scene.neighbours)
+    slot = pl["slot"]
+    odd = sorted(j for v in pl["recv"].values() for j in v)[0] if (mode.endswith("refuse") and rank == 1) else None
+    lists = {slot[k]: _kf_list(k, H, W, moved=(k == odd)) for k in pl["inputs"]}
+    # the wire format of the job: the longest list anywhere, rounded up to 64 (one all-reduce, as agree_compact_wire does)
+    t = torch.tensor([max(v.size for v in lists.values())], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    entries = (int(t.item()) + 63) // 64 * 64
+    pool = torch.zeros((pl["n_slots"], H, W, 2), dtype=torch.float32)
+    for k in pl["own"]:
+        pool[slot[k]] = torch.from_numpy(_kf_map(k, lists[slot[k]], H, W))
+    codec = shard.HostCompactCodec(pool, lists, entries)
+    if mode.startswith("allgather"):
+        shard.allgather_boundary_compact(codec, pl)
+    else:
+        shard.exchange_halo_compact(codec, pl)
+    ok = entries * 2 < H * W  # the payload is smaller than the plane it stands for
+    for k in pl["inputs"]:
+        want = _kf_map(k, _kf_list(k, H, W), H, W)
+        if k == odd:  # refused: counted, and the plane keeps what it held (zeros)
+            ok = ok and codec.refused == 1 and not bool(pool[slot[k]].any())
+        else:
+            ok = ok and bool((pool[slot[k]].numpy().view(np.uint32) == want.view(np.uint32)).all())
+    if odd is None:
+        ok = ok and codec.refused == 0
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
 def _run_world(world, n_total, mode, n_nbr=4):
+    if "compact" in mode:
+        return _run_world_with(_compact_worker, world, n_total, mode, n_nbr, 24, 32)
+    return _run_world_with(_worker, world, n_total, mode, n_nbr, 6, 8)
+
+
+def _run_world_with(target, world, n_total, mode, n_nbr, H, W):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, 6, 8, out, mode, n_nbr)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, n_total, H, W, out, mode, n_nbr)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -159,6 +226,40 @@ def test_boundary_allgather_gloo_world3(pkg):
     """the default exchange: an all-gather of the boundary keyframes only (padded to a common count: the end ranks
     have half as many), world_size 3 on gloo -- every map a rank's K4 reads arrives in its local slot"""
     _run_world(3, 24, "allgather", n_nbr=6)
+
+
+def test_compact_wire_gloo_world2(pkg):
+    """the compact wire format ({rho,sigma} of the list entries + length / hash header) crosses a process boundary:
+    point-to-point form, world_size 2 on gloo, host arrays (the numpy statement of k_pack_lists / k_unpack_lists)"""
+    _run_world(2, 12, "halo_compact")
+
+
+def test_compact_wire_gloo_world3_allgather(pkg):
+    _run_world(3, 24, "allgather_compact", n_nbr=6)
+
+
+def test_compact_wire_refuses_a_different_list(pkg):
+    """a receiver whose list of a keyframe differs from the sender's -- SAME length, one pixel moved: only the hash can
+    tell -- refuses that map, counts it and leaves the plane alone"""
+    _run_world(2, 12, "halo_compact_refuse")
+
+
+def test_compact_codec_roundtrip(pkg):
+    shard = pkg.shard
+    H, W = 24, 32
+    lst = _kf_list(7, H, W)
+    m = _kf_map(7, lst, H, W)
+    entries = (lst.size + 63) // 64 * 64
+    p = shard.pack_compact(m, lst, entries)
+    assert p.shape == (entries + shard.XCHG_HEADER, 2) and int(p.view(np.uint32)[entries, 0]) == lst.size
+    back = np.zeros_like(m)
+    assert shard.unpack_compact(p, lst, entries, back) and (back.view(np.uint32) == m.view(np.uint32)).all()
+    other = _kf_list(7, H, W, moved=True)
+    assert other.size == lst.size and shard.list_hash(other) != shard.list_hash(lst)
+    untouched = np.zeros_like(m)
+    assert not shard.unpack_compact(p, other, entries, untouched) and not untouched.any()
+    with pytest.raises(ValueError):
+        shard.pack_compact(m, lst, 64)
 
 
 def test_boundary_allgather_lists(pkg):

@@ -39,7 +39,21 @@ for rep in range(3):
         if rep:
             t_recon.append((t1 - t0) * 1e3)
             t_rest.append((t2 - t1) * 1e3)
-for name, t in (("SemiDenseRecon (K1-K3), 1 keyframe x %d neighbours" % N, t_recon), ("inter-check + point set (K4-K5)", t_rest)):
+# ingest of ONE new keyframe from host memory (what the fork's Tracking -> Modeler::AddFrameImage hand-over costs per
+# keyframe): H2D + device pre-pass + records + pixel list, wall clock until the device has finished; pageable and pinned
+host_im = scene.render(5, device="cuda")[0].cpu().numpy()
+pin_im = eng.host_alloc((H, W))
+pin_im[...] = host_im
+t_up, t_up_pin = [], []
+for rep in range(60):
+    for src, acc in ((host_im, t_up), (pin_im, t_up_pin)):
+        t0 = time.perf_counter()
+        eng.upload_image(n_kf - 1, src, scene.K(), scene.Tcw(5))
+        eng.synchronize()
+        if rep >= 10:
+            acc.append((time.perf_counter() - t0) * 1e3)
+for name, t in (("SemiDenseRecon (K1-K3), 1 keyframe x %d neighbours" % N, t_recon), ("inter-check + point set (K4-K5)", t_rest),
+                ("sdm_upload_image, 1 keyframe (pageable source)", t_up), ("sdm_upload_image, 1 keyframe (pinned source)", t_up_pin)):
     t = np.array(t)
     print("%-52s mean %.3f ms  p50 %.3f  p99 %.3f" % (name, t.mean(), np.percentile(t, 50), np.percentile(t, 99)))
 eng.close()
