@@ -94,11 +94,11 @@ def self_launch(args):
 
 
 def source_hash():
-    """hash of the kernel sources (device code: sdm_device.h, sdm_kernels.h): ties a committed PMC traffic figure to the
+    """hash of the kernel sources (device code: sdm_device.h, sdm_kernels.h, sdm_ingest.h): ties a committed PMC traffic figure to the
     kernels it was measured on; the host side of the engine and the exchange (sdm_engine.hip, sdm_comm.h) are not part of it"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "orb-slam-free-space-carving_amd", "csrc")
-    for f in ("sdm_device.h", "sdm_kernels.h"):
+    for f in ("sdm_device.h", "sdm_kernels.h", "sdm_ingest.h"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
