@@ -12,10 +12,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -212,7 +215,7 @@ int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
 // ---- ingest chunks ---------------------------------------------------------------------------------------------------------
 // chunk buffer b is free: the host may rewrite its pinned blocks (their H2D copies have finished) and the upload stream may
 // overwrite its device blocks once the kernels that read them have finished
-int ingest_acquire(sdm_ctx* c, int b)
+int ingest_acquire(sdm_ctx* c, int b, hipStream_t copy_stream)
 {
     sdm_ctx::IngestBuf& B = c->ing[b];
     if (B.copied_pending) {
@@ -220,20 +223,20 @@ int ingest_acquire(sdm_ctx* c, int b)
         B.copied_pending = false;
     }
     if (B.consumed_pending) {
-        HIP_TRY(hipStreamWaitEvent(c->up_stream, B.consumed, 0));
+        if (copy_stream != c->stream) HIP_TRY(hipStreamWaitEvent(copy_stream, B.consumed, 0));  // (same stream: ordered anyway)
         B.consumed_pending = false;
     }
     return SDM_OK;
 }
 // the chunk's item table goes up behind whatever image copies were queued on the upload stream; the compute stream waits
 // for all of it
-int ingest_publish(sdm_ctx* c, int b, int m)
+int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream)
 {
     sdm_ctx::IngestBuf& B = c->ing[b];
-    HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, c->up_stream));
-    HIP_TRY(hipEventRecord(B.copied, c->up_stream));
+    HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, copy_stream));
+    HIP_TRY(hipEventRecord(B.copied, copy_stream));
     B.copied_pending = true;
-    HIP_TRY(hipStreamWaitEvent(c->stream, B.copied, 0));
+    if (copy_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, B.copied, 0));
     return SDM_OK;
 }
 // list lengths of the chunk's slots -> pinned host mirror (one copy when the slots are consecutive)
@@ -284,13 +287,13 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
         const int m = std::min(c->ing_cap, n - i0);
         const int b = c->ing_next;
         c->ing_next ^= 1;
-        if ((rc = ingest_acquire(c, b))) return rc;
+        if ((rc = ingest_acquire(c, b, c->stream))) return rc;
         for (int i = 0; i < m; i++) {
             IngestItem& it = c->ing[b].h_items[i];
             memset(&it, 0, sizeof(it));
             it.slot = slots[i0 + i];
         }
-        if ((rc = ingest_publish(c, b, m))) return rc;
+        if ((rc = ingest_publish(c, b, m, c->stream))) return rc;
         if ((rc = ingest_launch(c, b, m, false, nullptr))) return rc;
         if ((rc = ingest_counts(c, m, slots + i0))) return rc;
     }
@@ -897,14 +900,19 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
 // ---- image ingest, batched (sdm_ingest.h) ------------------------------------------------------------------------------------
 namespace {
 
-bool host_pinned(const void* p)
+// Pinned blocks handed out by sdm_host_alloc, [base, base + size): images inside one are read in place by the copy engine.
+// (Asking the driver about every image pointer instead -- hipPointerGetAttributes -- costs a system call that now and then
+// takes milliseconds for ordinary memory; memory the application pinned by other means is simply staged like pageable memory.)
+std::mutex g_pinned_mutex;
+std::map<const uint8_t*, size_t> g_pinned_blocks;
+bool host_pinned(const void* p, size_t bytes)
 {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();  // an ordinary (pageable) host pointer is "invalid value" to the runtime
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    const uint8_t* q = (const uint8_t*)p;
+    auto it = g_pinned_blocks.upper_bound(q);
+    if (it == g_pinned_blocks.begin()) return false;
+    --it;
+    return q >= it->first && q + bytes <= it->first + it->second;
 }
 
 // Staging copies of pageable images into the pinned ring, chunk after chunk, shared between the calling thread and a few
@@ -1013,18 +1021,26 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
     std::vector<char> pinned((size_t)n, 0);
     size_t pageable_bytes = 0;
     for (int i = 0; i < n && !on_device; i++) {
-        pinned[i] = host_pinned(images[i]) ? 1 : 0;
+        pinned[i] = host_pinned(images[i], bytes) ? 1 : 0;
         if (!pinned[i]) pageable_bytes += bytes;
     }
     const int hw = (int)std::thread::hardware_concurrency();
     const int n_chunks = (n + cap - 1) / cap;
     Stager stager((pageable_bytes >= ((size_t)2 << 20) && hw >= 4) ? std::min(4, hw / 2) : 1, n_chunks);
+    // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
+    // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
+    const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
+    const bool dbg = getenv("SDM_DEBUG_INGEST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tdbg[6] = {0, 0, 0, 0, 0, 0};
     for (int i0 = 0, chunk = 0; i0 < n; i0 += cap, chunk++) {
         const int m = std::min(cap, n - i0);
         const int b = c->ing_next;
         c->ing_next ^= 1;
         sdm_ctx::IngestBuf& B = c->ing[b];
-        if ((rc = ingest_acquire(c, b))) return rc;
+        if (dbg) tdbg[0] = now();
+        if ((rc = ingest_acquire(c, b, cs))) return rc;
+        if (dbg) tdbg[1] = now();
         uint8_t* d_dst = q ? B.d_src : B.d_img;
         uint8_t* h_dst = q ? B.h_src : B.h_ring;
         for (int i = 0; i < m; i++) {
@@ -1044,17 +1060,18 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
                 for (int i = 0; i < m;) {
                     int r = 1;
                     while (i + r < m && images[i0 + i + r] == images[i0 + i + r - 1] + bytes) r++;
-                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], (size_t)r * bytes, hipMemcpyHostToDevice,
-                                           c->up_stream));
+                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], (size_t)r * bytes, hipMemcpyHostToDevice, cs));
                     i += r;
                 }
                 direct = true;
             } else {
                 stager.stage(chunk, h_dst, images + i0, m, bytes);
-                HIP_TRY(hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, c->up_stream));
+                HIP_TRY(hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, cs));
             }
         }
-        if ((rc = ingest_publish(c, b, m))) return rc;
+        if (dbg) tdbg[2] = now();
+        if ((rc = ingest_publish(c, b, m, cs))) return rc;
+        if (dbg) tdbg[3] = now();
         for (int i = 0; i < m; i++) {
             const int slot = slots[i0 + i];
             reset_slot_state(c, slot);
@@ -1062,7 +1079,14 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
             c->act_lambdaG[slot] = c->dprm.lambdaG;
         }
         if ((rc = ingest_launch(c, b, m, true, q))) return rc;
+        if (dbg) tdbg[4] = now();
         if ((rc = ingest_counts(c, m, slots + i0))) return rc;
+        if (dbg) {
+            tdbg[5] = now();
+            if (tdbg[5] - tdbg[0] > 2.0)
+                fprintf(stderr, "[sdm ingest] slow chunk: acquire %.3f  images %.3f  publish %.3f  launch %.3f  counts %.3f ms\n",
+                        tdbg[1] - tdbg[0], tdbg[2] - tdbg[1], tdbg[3] - tdbg[2], tdbg[4] - tdbg[3], tdbg[5] - tdbg[4]);
+        }
         last = b;
     }
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
@@ -1142,12 +1166,19 @@ void* sdm_host_alloc(size_t bytes)
         (void)hipGetLastError();
         return nullptr;
     }
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    g_pinned_blocks[(const uint8_t*)p] = std::max<size_t>(bytes, 1);
     return p;
 }
 
 void sdm_host_free(void* p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pinned_blocks.erase((const uint8_t*)p);
+    }
+    (void)hipHostFree(p);
 }
 
 int sdm_set_pose(sdm_ctx* c, int slot, const float Tcw[12])
