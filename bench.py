@@ -434,6 +434,16 @@ def main():
                 eng.comm_destroy()
             except Exception:  # noqa: BLE001
                 pass
+            eng.compact_entries = 0  # the fall-back moves whole maps (shard.pipeline_step looks at this)
+            try:
+                eng.exchange_compact(0)
+            except Exception:  # noqa: BLE001
+                pass
+
+    if exchanging and rehearse and args.wire == "compact":
+        # the rehearsal moves the compact payloads as well: packed and scattered by the engine's kernels, staged through
+        # host memory, gloo in between (shard.EngineCompactCodec) -- the wire format's control flow, not its speed
+        wire_entries = pkg.shard.agree_compact_wire(eng, pl)
 
     # PCIe-inclusive variant (reported in DESIGN.md, never `value`): the same keyframes handed over as HOST gray images
     # (H2D copy + device pre-pass + record packing + pixel lists): one sdm_upload_images_batch call for the block -- from
@@ -576,14 +586,16 @@ def main():
             "allgather_full": (world - 1) * pl["count"],
             "halo": sum(len(v) for v in pl["recv"].values())}
         out["config"]["exchange_wire"] = (
-            {"format": "{rho,sigma} of the keyframe's active-list entries (sdm_exchange_compact); the receiver scatters them "
-                       "through its own list of that keyframe", "entries_per_map": wire_entries,
+            {"format": "{rho,sigma} of the keyframe's active-list entries + list length / hash header (sdm_exchange_compact); "
+                       "the receiver scatters them through its own list of that keyframe" +
+                       (" -- host-staged over gloo in this rehearsal" if rehearse else ""), "entries_per_map": wire_entries,
              "bytes_per_map": 8 * wire_entries, "whole_map_bytes": 8 * P}
             if wire_entries > 0 else {"format": "whole maps", "bytes_per_map": 8 * P})
     if transport_note:
         out["transport_note"] = transport_note
     if rehearse:
         out["rehearsal"] = "all ranks on GPU 0, gloo, host-staged exchange: control-flow dry run, not a measurement"
+        out["staged_refused_maps"] = getattr(eng, "staged_refused", 0)
     if stats:
         out["scan"] = scan_record(stats, k1_avg_ms)
 

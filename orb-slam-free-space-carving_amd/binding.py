@@ -404,6 +404,7 @@ class Engine:
         self._check(self.lib.sdm_comm_init(self.ctx, buf, world, rank))
 
     def comm_destroy(self):
+        self.compact_entries = 0  # sdm_comm_destroy resets the wire format to whole maps, whatever else it reports
         self._check(self.lib.sdm_comm_destroy(self.ctx))
 
     def comm_info(self):
