@@ -379,8 +379,11 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 12 (lost: +1.2 %, EXPERIMENTS.md) wave-uniform scan plan: the wave's longest range is covered by batches of 4 and 3
 //        records (exact for every length >= 6) instead of by batches of 4 until the last lane is done -- a padding slot only
 //        costs ~13 vector instructions (the wave branches past the gates), less than the plan's wave-wide maximum
+// bit 13 arg-min of the scan from an APPROXIMATE matching cost in float (one FMA), the exact cost only where two costs
+//        are too close to call (scan_batch; sdm_selftest(2) bounds the approximation) -- clean pairs with the default theta
+// bit 14 the arg-min's four state updates as exec-masked moves (a real branch region) instead of four v_cndmask
 #ifndef SDM_K1_OPT
-#define SDM_K1_OPT 0x27f
+#define SDM_K1_OPT 0x227f
 #endif
 
 // what one search reads of its PairConst, as float indices into the block `cv` points at: the PairConst itself
@@ -403,6 +406,24 @@ __device__ __forceinline__ float match_cost1(float pe2, float ge2, const DevPara
     if (__builtin_expect(risky, 0)) s = (double)pe2 + (double)ge2 / prm.theta_var;
     return (float)s;
 }
+
+// ---- arg-min of the scan without the exact cost (SDM_K1_OPT bit 13) ------------------------------------------------------
+// The scan only ever COMPARES matching costs (PM.cc:437 "err < old_err", PM.cc:446 "old_err < 1000000"): the value itself
+// feeds nothing.  e~ = fma(ge2, (float)(1/THETA), pe2) is within 4 float steps of the reference's
+// err = (float)((double)pe2 + (double)ge2 / THETA) for every non-negative pe2, ge2 (one rounding of the exact sum with a
+// constant that is off by 2^-24 relative, against the reference's float rounding of a sum that is exact to 2^-52: at most
+// 1.5 ulp + 1 ulp apart where ulps differ by a factor of two; sdm_selftest(2) measures the distance).  Non-negative floats
+// order like their bit patterns, so when bits(e~_new) and bits(e~_best) differ by more than COST_BAND steps the exact
+// costs compare the same way (strictly); inside the band both exact costs are evaluated and compared as the reference
+// does -- ties and near-ties only.  NaN costs (NaN records) are never "better" under either statement; an Inf cost lies
+// 2^23 steps above any best (<= 1e6).  The literal keeps the FMA in the full-rate issue class (no scalar-register operand).
+constexpr float INV_THETA_DEFAULT_F = (float)(1.0 / 0.23);
+constexpr unsigned COST_BAND = 16u;
+__device__ __forceinline__ float match_cost_ref(float pe2, float ge2, const DevParams& prm)  // PM.cc:436 as written
+{
+    return (float)((double)pe2 + (double)ge2 / prm.theta_var);
+}
+__device__ __forceinline__ float match_cost_approx(float pe2, float ge2) { return __builtin_fmaf(ge2, INV_THETA_DEFAULT_F, pe2); }
 
 // lerp weights of bilinear<T> at integer x (PM.cc:40-59): y0w = (floor(yf)+1) - yf, y1w = 1 - y0w.
 // (floor(yf)+1) - yf = 1 - (yf - floor(yf)) in real arithmetic, yf - floor(yf) is exactly representable (what v_fract
@@ -571,6 +592,25 @@ __device__ __forceinline__ void scan_batch(const ScanConst& q, int u0, float u0f
         const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
         float pe = q.pixel - rec_lerp_im_w(r, y0w);        // PM.cc:433
         float ge = q.grad1 - rec_lerp_grad_w(r, y0w);      // PM.cc:434
+#if SDM_K1_OPT & 0x2000
+        if (CLEAN) {  // (this instantiation also implies theta_var == 0.23)
+            // S.old_err holds the APPROXIMATE cost of the best candidate so far (1e6 exactly before the first)
+            const float e = match_cost_approx(pe * pe, ge * ge);
+            bool better = e < S.old_err;
+            if (__builtin_expect((__float_as_uint(e) - __float_as_uint(S.old_err) + COST_BAND) <= 2u * COST_BAND, 0))
+                better = match_cost_ref(pe * pe, ge * ge, prm) < match_cost_ref(S.best_pe * S.best_pe, S.best_ge * S.best_ge, prm);
+            if (better) {
+#if SDM_K1_OPT & 0x4000
+                asm volatile("" ::: "memory");  // not if-convertible: the four moves run under the exec mask
+#endif
+                S.best_pixel = uj;
+                S.old_err = e;
+                S.best_pe = pe;
+                S.best_ge = ge;
+            }
+            continue;
+        }
+#endif
 #if SDM_K1_OPT & 0x08
         float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
 #else
@@ -678,7 +718,9 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     // closed-form gates need d < 360 and the default thresholds; with other thresholds the limit is -Inf and
     // every candidate takes the reference statement (a float limit keeps the test free of a uniform-bool VGPR)
     const float gate_lim = prm.default_gates ? 360.0f : -__builtin_inff();
-    ScanState S = {1000000.0f, 0.f, 0.f, 0};
+    // "no candidate yet": cost 1e6 (PM.cc:396) -- pe = 1000, ge = 0 ARE that cost under the exact statement, which is what the
+    // approximate arg-min (bit 13) evaluates when its first near-tie involves the initial state; best_pixel = -1 marks it
+    ScanState S = {1000000.0f, 1000.0f, 0.f, -1};
     const float hlim2 = (float)(H - 2);
     const char* __restrict__ nbase = reinterpret_cast<const char*>(nrec);
 #if SDM_ABLATE == 10
@@ -709,7 +751,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         const int Lmax = wave_max_nonneg(max(hi - lo + 1, 0));  // wave-uniform (a scalar register)
         if (Lmax > 0) {
 #if SDM_K1_OPT & 0x02
-            if (clean && prm.default_gates)  // wave-uniform
+            if (clean && prm.default_gates && prm.fast_theta_div)  // wave-uniform
                 scan_planned<STATS, true>(sc, lo, Lmax, prm, S, st);
             else
 #endif
@@ -718,17 +760,19 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         if (!live) return false;
     } else {
 #if SDM_K1_OPT & 0x02
-        if (clean && prm.default_gates)  // wave-uniform
+        if (clean && prm.default_gates && prm.fast_theta_div)  // wave-uniform
             scan_segment<STATS, true>(sc, lo, prm, S, st);
         else
 #endif
             scan_segment<STATS, false>(sc, lo, prm, S, st);
     }
-    const float old_err = S.old_err, best_pe = S.best_pe, best_ge = S.best_ge;
+    const float best_pe = S.best_pe, best_ge = S.best_ge;
     const int best_pixel = S.best_pixel;
-    if (!(old_err < 1000000.0f)) return false;  // PM.cc:446
+    // PM.cc:446 "old_err < 1000000": old_err starts at 1e6 and only ever takes a smaller cost, so the test says "some
+    // candidate was taken" (uj >= 0)
+    if (best_pixel < 0) return false;
 #if SDM_ABLATE == 2
-    rho_o = old_err + best_pe + (float)best_pixel;
+    rho_o = S.old_err + best_pe + (float)best_pixel;
     sigma_o = best_ge + 1.0f;
     return true;
 #endif

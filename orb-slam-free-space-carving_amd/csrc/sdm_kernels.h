@@ -1720,6 +1720,15 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_cost(DevParams prm, int iter
         if (!(ref == got || (ref != ref && got != got))) cnt++;
         got = match_cost(pe2s, ge2s, prm);
         if (!(ref == got || (ref != ref && got != got))) cnt++;
+        // the scan's approximate cost (SDM_K1_OPT bit 13) must stay within COST_BAND / 4 float steps of the reference value
+        // (two costs further than COST_BAND steps apart then compare like their exact values): default theta only
+        if (prm.fast_theta_div) {
+            const float r1 = (float)((double)pe2 + (double)ge2 / prm.theta_var);
+            const unsigned d1 = __float_as_uint(match_cost_approx(pe2, ge2)) - __float_as_uint(r1) + COST_BAND / 4u;
+            const unsigned d2 = __float_as_uint(match_cost_approx(pe2s, ge2s)) - __float_as_uint(ref) + COST_BAND / 4u;
+            if (r1 == r1 && d1 > COST_BAND / 2u) cnt++;
+            if (ref == ref && d2 > COST_BAND / 2u) cnt++;
+        }
         double sfast = (double)pe2 + (double)ge2 * prm.inv_theta;
         unsigned lo = (unsigned)__double2loint(sfast);
         if (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) hits++;
