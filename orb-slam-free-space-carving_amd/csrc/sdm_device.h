@@ -39,9 +39,10 @@ struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of th
     float tx, tz;               // t21 x and z, PM.cc:860 == 891 == 644
     float rot;                  // median in-plane rotation, PM.cc:170-179
     float istd;                 // neighbour's I_stddev, PM.cc:457
-    int clean;                  // every angle the scan's two gates see lies in [0,360]: both keyframes' GradTheta planes
+    int clean;                  // bit 0: every angle the scan's two gates see lies in [0,360]: both keyframes' GradTheta planes
                                 // (checked when the records are packed) and rot in [-360,360] -- the closed-form gates
-                                // then hold for every candidate and the scan drops their per-candidate precondition
+                                // then hold for every candidate and the scan drops their per-candidate precondition;
+                                // bit 1: line_quot_safe(F) -- the line's quotients need no per-lane guard
     // -- the rest (K4, set-up) --
     float Ry[3];                // R21 row 1
     float ty;
@@ -382,8 +383,12 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 // bit 13 arg-min of the scan from an APPROXIMATE matching cost in float (one FMA), the exact cost only where two costs
 //        are too close to call (scan_batch; sdm_selftest(2) bounds the approximation) -- clean pairs with the default theta
 // bit 14 the arg-min's four state updates as exec-masked moves (a real branch region) instead of four v_cndmask
+// bit 15 the line's two quotients a/b, c/b (PM.cc:393, 407) in reciprocal form (one v_rcp_f32 + FMA steps, shared) for pairs
+//        whose F12 entries are +0 or of moderate magnitude (PairConst::clean bit 1, line_quot_safe): no per-lane guard
+// bit 16 sqrtf(ustar_var) (PM.cc:818) as v_rsq_f32 + one FMA residual step, exact for every x in [2^-100, 2^127)
+//        (tools/ubench/exact_ops.hip walks all positive floats; sdm_selftest(6) repeats it)
 #ifndef SDM_K1_OPT
-#define SDM_K1_OPT 0x227f
+#define SDM_K1_OPT 0x1a27f
 #endif
 
 // what one search reads of its PairConst, as float indices into the block `cv` points at: the PairConst itself
@@ -501,6 +506,76 @@ __device__ __forceinline__ float wrap_once_360(float a)
 #else
     return wrap_once_360_ref(a);
 #endif
+}
+
+// ---- float quotients in reciprocal form (K4) ------------------------------------------------------------------
+// a/b as q = a*r with two FMA residual corrections (Markstein), r = 1/b correctly rounded (rcp_fast: v_rcp_f32 +
+// one FMA step, see rcp_exact).  Bit-identical to the IEEE quotient whenever |a| and |b| lie in [2^-40, 2^41) and
+// b's significand is not all ones -- quot_window_ok states exactly that; K4 folds the same test over all operands
+// of a neighbour into running integer min/max (NaN and Inf land above the window) instead of testing per quotient.
+// sdm_selftest(5) compares quot_fast with the division over 2^33 operand pairs in and around the window.
+constexpr unsigned QUOT_MAG_LO = 87u << 23;          // 2^-40
+constexpr unsigned QUOT_MAG_HI = (168u << 23) - 1u;  // just below 2^41
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ float rcp_fast(float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float quot_fast(float a, float b, float r)
+{
+    float q0 = a * r;
+    float e0 = __builtin_fmaf(-q0, b, a);
+    float q1 = __builtin_fmaf(e0, r, q0);
+    float e1 = __builtin_fmaf(-q1, b, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+__device__ __forceinline__ bool quot_window_ok(float a, float b)
+{
+    const unsigned ua = absbits(a), ub = absbits(b);
+    return (ua >= QUOT_MAG_LO) & (ua <= QUOT_MAG_HI) & (ub >= QUOT_MAG_LO) & (ub <= QUOT_MAG_HI) &
+           ((__float_as_uint(b) & 0x7FFFFFu) != 0x7FFFFFu);
+}
+
+// ---- correctly rounded sqrtf without the compiler's scaling / +-1 ulp selection (SDM_K1_OPT bit 16) --------------------------
+// y0 = x * rsq(x), one residual step y0 + (x - y0^2) * (rsq(x)/2): bit-identical to the IEEE square root for EVERY float in
+// [2^-102, 2^128) on gfx950 (exhaustive: tools/ubench/exact_ops.hip, profiles/r04_exact_ops.txt; the 1.8 M mismatches all
+// lie below 2^-102, where the residual underflows).  5 instructions (one transcendental) against 17.  Anything outside
+// [2^-100, 2^127) -- zero, denormal, negative, Inf, NaN -- takes sqrtf.
+__device__ __forceinline__ float sqrt_exact(float x)
+{
+#if SDM_K1_OPT & 0x10000
+    if (__builtin_expect((__float_as_uint(x) - (27u << 23)) >= ((254u - 27u) << 23), 0)) return sqrtf(x);
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float y0 = x * r, h = 0.5f * r;
+    const float e = __builtin_fmaf(-y0, y0, x);
+    return __builtin_fmaf(e, h, y0);
+#else
+    return sqrtf(x);
+#endif
+}
+
+// ---- the epipolar line's quotients without a per-lane guard (SDM_K1_OPT bit 15) ----------------------------------------------
+// a, b, c = (x*F[0+k] + y*F[3+k]) + F[6+k] with integer pixel coordinates 0 <= x, y < 2^16.  If every entry of F12 is +0 or
+// has a magnitude in [2^-36, 2^20] (line_quot_safe, decided once per pair), then
+//   * each of a, b, c is a multiple of 2^-59 (products of an integer and a float keep the float's grid; sums and
+//     roundings keep the coarser grid) and at most 3 * 2^36 in magnitude: zero, or inside [2^-59, 2^38];
+//   * none of them is -0: the last addend F[6+k] is +0 or non-zero, and a sum that cancels rounds to +0;
+//   * for b != 0 the reciprocal (v_rcp_f32 + one FMA step: correctly rounded, sdm_selftest(6)) and every quotient are
+//     normal, all residuals stay above 2^-90: quot_fast is the IEEE quotient (two Markstein steps from a correctly rounded
+//     reciprocal; sdm_selftest(5) covers the operand range, all-ones divisor significands included -- the exception
+//     quot_window_ok makes for them is not needed: tools/ubench/exact_ops.hip, 2 * 10^10 quotients, no mismatch);
+//     a zero numerator gives the quotient's zero with the IEEE sign (+0 numerator);
+//   * b == 0 makes both forms produce Inf or NaN for a/b: the search is rejected by PM.cc:393 either way, c/b is not used.
+__device__ __forceinline__ bool line_quot_safe(const float* F)
+{
+    bool ok = true;
+    for (int i = 0; i < 9; i++) {
+        const unsigned u = __float_as_uint(F[i]), mag = u & 0x7FFFFFFFu;
+        ok = ok && (u == 0u || (mag >= ((127u - 36u) << 23) && mag <= ((127u + 20u) << 23)));
+    }
+    return ok;
 }
 
 struct ScanState {
@@ -692,12 +767,27 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     float a = (float)x * F[0] + (float)y * F[3] + F[6];  // PM.cc:389-391
     float b = (float)x * F[1] + (float)y * F[4] + F[7];
     float c = (float)x * F[2] + (float)y * F[5] + F[8];
+#if SDM_K1_OPT & 0x8000
+    float ab, cb;
+    if (clean & 2) {  // wave-uniform: line_quot_safe(F12)
+        const float rb = rcp_fast(b);
+        ab = quot_fast(a, b, rb);
+        cb = quot_fast(c, b, rb);
+    } else {
+        ab = a / b;
+        cb = c / b;
+    }
+    // PM.cc:393; a NaN line yields no hypothesis
+    bool live = on & (ab >= -4) & (ab <= 4);
+    if (!PLAN && !live) return false;
+#else
     float ab = a / b;
     // PM.cc:393; a NaN line yields no hypothesis.  With PLAN the lanes stay together up to the scan (a lane that is out
     // gets an empty range) so that the wave-wide maximum below sees all of them
     bool live = on & (ab >= -4) & (ab <= 4);
     if (!PLAN && !live) return false;
     float cb = c / b;
+#endif
 
     float rxxp = row_dot_xp(cv + CV_RX, xp0, xp1);
     float rzxp = row_dot_xp(cv + CV_RZ, xp0, xp1);
@@ -751,7 +841,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         const int Lmax = wave_max_nonneg(max(hi - lo + 1, 0));  // wave-uniform (a scalar register)
         if (Lmax > 0) {
 #if SDM_K1_OPT & 0x02
-            if (clean && prm.default_gates && prm.fast_theta_div)  // wave-uniform
+            if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
                 scan_planned<STATS, true>(sc, lo, Lmax, prm, S, st);
             else
 #endif
@@ -760,7 +850,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         if (!live) return false;
     } else {
 #if SDM_K1_OPT & 0x02
-        if (clean && prm.default_gates && prm.fast_theta_div)  // wave-uniform
+        if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
             scan_segment<STATS, true>(sc, lo, prm, S, st);
         else
 #endif
@@ -803,7 +893,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 
     // ComputeInvDepthHypothesis PM.cc:806-829
     float d0 = pixel_depth(ustar, fx, cx, rzxp, rxxp, tx, tz);
-    float s = sqrtf(ustar_var);
+    float s = sqrt_exact(ustar_var);
     float dmin = pixel_depth(ustar - s, fx, cx, rzxp, rxxp, tx, tz);
     float dmax = pixel_depth(ustar + s, fx, cx, rzxp, rxxp, tx, tz);
     float e1 = fabsf(dmax - d0), e2 = fabsf(dmin - d0);
@@ -891,36 +981,6 @@ __device__ __forceinline__ float rcp_exact(float b)
     const float r = __builtin_amdgcn_rcpf(b);
     const float e = __builtin_fmaf(-b, r, 1.0f);
     return __builtin_fmaf(e, r, r);
-}
-
-// ---- float quotients in reciprocal form (K4) ------------------------------------------------------------------
-// a/b as q = a*r with two FMA residual corrections (Markstein), r = 1/b correctly rounded (rcp_fast: v_rcp_f32 +
-// one FMA step, see rcp_exact).  Bit-identical to the IEEE quotient whenever |a| and |b| lie in [2^-40, 2^41) and
-// b's significand is not all ones -- quot_window_ok states exactly that; K4 folds the same test over all operands
-// of a neighbour into running integer min/max (NaN and Inf land above the window) instead of testing per quotient.
-// sdm_selftest(5) compares quot_fast with the division over 2^33 operand pairs in and around the window.
-constexpr unsigned QUOT_MAG_LO = 87u << 23;          // 2^-40
-constexpr unsigned QUOT_MAG_HI = (168u << 23) - 1u;  // just below 2^41
-__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
-__device__ __forceinline__ float rcp_fast(float b)
-{
-    const float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ float quot_fast(float a, float b, float r)
-{
-    float q0 = a * r;
-    float e0 = __builtin_fmaf(-q0, b, a);
-    float q1 = __builtin_fmaf(e0, r, q0);
-    float e1 = __builtin_fmaf(-q1, b, a);
-    return __builtin_fmaf(e1, r, q1);
-}
-__device__ __forceinline__ bool quot_window_ok(float a, float b)
-{
-    const unsigned ua = absbits(a), ub = absbits(b);
-    return (ua >= QUOT_MAG_LO) & (ua <= QUOT_MAG_HI) & (ub >= QUOT_MAG_LO) & (ub <= QUOT_MAG_HI) &
-           ((__float_as_uint(b) & 0x7FFFFFu) != 0x7FFFFFu);
 }
 
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.

@@ -115,7 +115,8 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     pc.ncy = m2.cy;
     // th_pi, theta2 in [0,360] and rot in [-360,360] => th_pi + rot in [-360,720] => one wrap lands in [0,360] => d2, d3
     // in [-360,360]: the closed-form gates of the scan hold for every candidate of this pair (sdm_device.h)
-    pc.clean = (theta_bad[ref_slots[r]] == 0 && theta_bad[nbr_slots[idx]] == 0 && pc.rot >= -360.0f && pc.rot <= 360.0f) ? 1 : 0;
+    pc.clean = ((theta_bad[ref_slots[r]] == 0 && theta_bad[nbr_slots[idx]] == 0 && pc.rot >= -360.0f && pc.rot <= 360.0f) ? 1 : 0) |
+               (line_quot_safe(pc.F) ? 2 : 0);
     pc.pad[0] = pc.pad[1] = pc.pad[2] = 0.f;
     pairs[idx] = pc;
     if (j == 0) {
@@ -1501,6 +1502,9 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_rcp(unsigned long long* __re
         const float b = __uint_as_float((unsigned)i);
         const float got = rcp_exact(b), want = 1.0f / b;
         if (!(__float_as_uint(got) == __float_as_uint(want) || (got != got && want != want))) cnt++;
+        // sqrt_exact (the search's sqrtf(ustar_var), SDM_K1_OPT bit 16) against sqrtf, every bit pattern as well
+        const float sg = sqrt_exact(b), sw = sqrtf(b);
+        if (!(__float_as_uint(sg) == __float_as_uint(sw) || (sg != sg && sw != sw))) cnt++;
         const float ab = fabsf(b);
         if ((ab >= 0x1p-125f) & (ab < 0x1p125f)) nf++;
     }
@@ -1792,6 +1796,18 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_quot(int iters, unsigned lon
         if ((pick & 127u) == 0) a = 0.0f;
         if ((pick & 127u) == 1) b = __uint_as_float(__float_as_uint(b) | 0x7FFFFFu);  // all-ones significand
         if ((pick & 127u) == 2) a = __uint_as_float(__float_as_uint(b) + ((pick >> 8) & 3u));  // a ~ b
+        // the epipolar line's quotients (SDM_K1_OPT bit 15) rely on a wider operand range, zero numerators and all-ones
+        // divisor significands: operands that are zero or in [2^-59, 2^38] (what line_quot_safe guarantees), b != 0
+        {
+            float a2 = __uint_as_float((ba & 0x807FFFFFu) | ((68u + (ba >> 23) % 97u) << 23));  // 2^-59 .. 2^37
+            float b2 = __uint_as_float((bb & 0x807FFFFFu) | ((68u + (bb >> 23) % 97u) << 23));
+            if ((pick & 127u) == 0) a2 = 0.0f;
+            if ((pick & 127u) == 1 || (pick & 127u) == 3) b2 = __uint_as_float(__float_as_uint(b2) | 0x7FFFFFu);
+            if ((pick & 127u) == 2) a2 = __uint_as_float(__float_as_uint(b2) + ((pick >> 8) & 3u));
+            const float q2 = quot_fast(a2, b2, rcp_fast(b2)), e2 = a2 / b2;
+            if (__float_as_uint(q2) != __float_as_uint(e2)) cnt++;
+            n++;
+        }
         if (!quot_window_ok(a, b)) continue;
         float q = quot_fast(a, b, rcp_fast(b));
         float e = a / b;
