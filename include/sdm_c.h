@@ -306,13 +306,19 @@ int sdm_get_timing(sdm_ctx *ctx, double ms_total[SDM_NUM_STAGES], long long laun
 /* device arithmetic self-tests: out[0] = mismatches (must be 0), out[1] = auxiliary count.
  * which 0: reciprocal+FMA division by theta_var vs plain division over all 2^32 float inputs;
  * which 1: reciprocal-prefiltered ChiTest vs the exact ChiTest around the 5.99 threshold;
- * which 2: fast matching cost (PM.cc:436) vs the reference expression incl. rounding midpoints;
+ * which 2: fast matching cost (PM.cc:436) vs the reference expression incl. rounding midpoints, and the distance of
+ *          the scan's approximate cost from it (at most 4 float steps: the arg-min of PM.cc:437 compares exactly);
  * which 3: closed-form angle gates (PM.cc:414-431) vs the reference statement;
  * which 4: GetFusion's shared-reciprocal double quotients (PM.cc:956-957) vs plain divisions;
- * which 5: reciprocal-form float quotients (K4, PM.cc:678-680,782-783) vs IEEE divisions inside the operand window;
- * which 6: reciprocal + one FMA step (K4/K5, PM.cc:769,777,793,349) vs IEEE 1/b over all 2^32 float inputs;
+ * which 5: reciprocal-form float quotients (K4, PM.cc:678-680,782-783; the line quotients PM.cc:393,407) vs IEEE
+ *          divisions inside the operand windows, all-ones divisor significands included;
+ * which 6: reciprocal + one FMA step (K4/K5, PM.cc:769,777,793,349) vs IEEE 1/b, and rsq + one FMA step (PM.cc:818)
+ *          vs sqrtf, over all 2^32 float inputs;
  * which 7: K4's straight-line per-neighbour body vs the reference statement (PM.cc:677-755,777-783) on 5*10^8
- *          random geometries / 2x2 tap patches; out[1] = cases whose fast result was accepted. */
+ *          random geometries / 2x2 tap patches; out[1] = cases whose fast result was accepted;
+ * which 8: scan identities (lerp weight, in-plane-rotation wrap) over all 2^32 float inputs;
+ * which 9: the same run as 7, reporting out[1] = projections (PM.cc:677-680, 695) decided by K4's approximate chain --
+ *          each compared with the plain-division chain's cell, validity and offset. */
 int sdm_selftest(sdm_ctx *ctx, int which, unsigned long long out[2]);
 /* name of the device the context runs on, e.g. "gfx950" */
 const char *sdm_device_arch(sdm_ctx *ctx);

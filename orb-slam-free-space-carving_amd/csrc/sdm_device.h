@@ -48,7 +48,7 @@ struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of th
     float ty;
     int nbr_slot;
     float nfx, nfy, ncx, ncy;  // neighbour intrinsics, PM.cc:675
-    float pad[3];
+    float pb[3];               // K4's approximate projection: error-bound constants (k4_proj_bounds, sdm_kernels.h)
 };
 static_assert(sizeof(PairConst) == 128, "PairConst must stay 128 B");
 
@@ -510,9 +510,13 @@ __device__ __forceinline__ float wrap_once_360(float a)
 
 // ---- float quotients in reciprocal form (K4) ------------------------------------------------------------------
 // a/b as q = a*r with two FMA residual corrections (Markstein), r = 1/b correctly rounded (rcp_fast: v_rcp_f32 +
-// one FMA step, see rcp_exact).  Bit-identical to the IEEE quotient whenever |a| and |b| lie in [2^-40, 2^41) and
-// b's significand is not all ones -- quot_window_ok states exactly that; K4 folds the same test over all operands
-// of a neighbour into running integer min/max (NaN and Inf land above the window) instead of testing per quotient.
+// one FMA step, see rcp_exact).  Bit-identical to the IEEE quotient whenever |a| and |b| lie in [2^-40, 2^41) --
+// quot_window_ok states exactly that; K4 folds the same test over all operands of a neighbour into running integer
+// min/max (NaN and Inf land above the window) instead of testing per quotient.  (Rounds 1-3 also excluded divisors whose
+// significand is all ones -- the case where a Newton iteration cannot deliver the correctly rounded reciprocal.  rcp_fast IS
+// correctly rounded for every divisor (sdm_selftest(6)), and with that Markstein's theorem has no exception:
+// tools/ubench/exact_ops.hip finds no mismatch over 2 * 10^10 quotients by all-ones divisors, and the scale invariance of
+// the sequence makes that sweep complete for the window.)
 // sdm_selftest(5) compares quot_fast with the division over 2^33 operand pairs in and around the window.
 constexpr unsigned QUOT_MAG_LO = 87u << 23;          // 2^-40
 constexpr unsigned QUOT_MAG_HI = (168u << 23) - 1u;  // just below 2^41
@@ -534,8 +538,7 @@ __device__ __forceinline__ float quot_fast(float a, float b, float r)
 __device__ __forceinline__ bool quot_window_ok(float a, float b)
 {
     const unsigned ua = absbits(a), ub = absbits(b);
-    return (ua >= QUOT_MAG_LO) & (ua <= QUOT_MAG_HI) & (ub >= QUOT_MAG_LO) & (ub <= QUOT_MAG_HI) &
-           ((__float_as_uint(b) & 0x7FFFFFu) != 0x7FFFFFu);
+    return (ua >= QUOT_MAG_LO) & (ua <= QUOT_MAG_HI) & (ub >= QUOT_MAG_LO) & (ub <= QUOT_MAG_HI);
 }
 
 // ---- correctly rounded sqrtf without the compiler's scaling / +-1 ulp selection (SDM_K1_OPT bit 16) --------------------------

@@ -492,7 +492,7 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     if (n > 0) {
         hipLaunchKernelGGL(k_pair_setup, dim3(blocks_for((long long)np)), dim3(BLOCK), 0, c->stream, c->d_meta,
                            c->d_ref_slots, c->d_nbr_slots, c->d_rot, c->d_mind, c->d_maxd, c->d_act_count, c->d_theta_bad,
-                           n_ref, n, c->d_refs, c->d_pairs);
+                           n_ref, n, c->W, c->H, c->d_refs, c->d_pairs);
     } else {
         hipLaunchKernelGGL(k_ref_setup, dim3(blocks_for(n_ref)), dim3(BLOCK), 0, c->stream, c->d_meta, c->d_ref_slots,
                            c->d_act_count, n_ref, c->d_refs);
@@ -1890,7 +1890,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     } else if (which == 5) {
         hipLaunchKernelGGL(k_selftest_quot, dim3(4096), dim3(BLOCK), 0, c->stream, 8192, c->d_stats + 5,
                            c->d_stats + 6);
-    } else if (which == 7) {
+    } else if (which == 7 || which == 9) {
         // scratch: one 3x2 {rho,sigma} patch and one constant block per thread
         const int blocks = 1024;
         float2* d_patch = nullptr;
@@ -1901,7 +1901,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
             return fail(SDM_EHIP, "selftest scratch allocation failed");
         }
         hipLaunchKernelGGL(k_selftest_k4, dim3(blocks), dim3(BLOCK), 0, c->stream, 2048, d_patch, d_pc, c->d_stats + 5,
-                           c->d_stats + 6);
+                           c->d_stats + 6, which == 9 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_stats + 5, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -81,6 +81,41 @@ __device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], uns
     return total;
 }
 
+// ---- K4's approximate projection: per-pair error-bound constants (PairConst::pb) -------------------------------------
+// K4 needs the projection (xj, yj) of PM.cc:677-680 only for the bounds test of PM.cc:695 and floor(): an approximation
+// decides both unless it lies within its error bound of an integer (0 and cols-1 / rows-1 are integers).  With
+// d = 2^-23, dp = RN(1/rho), r~ = v_rcp_f32(t2~) and the approximate chain
+//     t_i~ = fma(n_i, dp, T_i)     u~ = nfx t0~ + ncx t2~ (the reference's operations)     xj~ = u~ r~
+// a term-by-term comparison with the reference chain RN(RN(n_i / rho) + T_i), ..., RN(u / t2) gives
+//     |t_i~ - t_i| <= d A_i,  A_i = 2 |n_i| dp + |T_i|        |u~ - u| <= 3 d B,  B = nfx A_0 + ncx A_2
+//     |xj~ - xj|  <= d (3 B + |xj| A_2) |r~| (1 + d) + 2 d |xj|
+// and with the per-pair bounds N_i >= |n_i| (over the whole reference image), C1 = max(nfx N_0 + ncx N_2, nfy N_1 + ncy N_2),
+// C2 = max(nfx |tx| + ncx |tz|, nfy |ty| + ncy |tz|), mc = min(ncx, ncy):  B <= 2 C1 dp + C2,  A_2 <= (2 C1 dp + C2) / mc.  So
+//     H = (pb[0] dp + pb[1]) |r~|,  pb[0] = 8 d C1, pb[1] = 4 d C2       (>= the absolute part, 25 % to spare)
+//     G = H pb[2] + 3 d,            pb[2] = 1.25 / (4 mc)                (>= the part proportional to |xj|, 25 % to spare)
+//     eps = H + G |xj~|
+// bounds |xj~ - xj| (the second-order term G eps is inside the spare: G >= 0.16 makes H >= 0.5 because mc >= 1 is
+// required, and then every value is within eps of an integer).  A lane whose xj~ or yj~ is within eps of an integer -- or
+// NaN, or beyond 2^23 -- takes the exact projection (inter_project); Inf / NaN constants (a pair that fails the sanity
+// test below) flag every lane.  sdm_selftest(7) compares cell and validity of unflagged lanes with the exact chain.
+__device__ inline void k4_proj_bounds(PairConst& pc, float X0max, float X1max)
+{
+    const float d = 0x1p-23f, s = 1.0f + 0x1p-18f;
+    const float N0 = (fabsf(pc.Rx[0]) * X0max + fabsf(pc.Rx[1]) * X1max + fabsf(pc.Rx[2])) * s;
+    const float N1 = (fabsf(pc.Ry[0]) * X0max + fabsf(pc.Ry[1]) * X1max + fabsf(pc.Ry[2])) * s;
+    const float N2 = (fabsf(pc.Rz[0]) * X0max + fabsf(pc.Rz[1]) * X1max + fabsf(pc.Rz[2])) * s;
+    const float fx = fabsf(pc.nfx), fy = fabsf(pc.nfy), cx = fabsf(pc.ncx), cy = fabsf(pc.ncy);
+    const float C1 = fmaxf(fx * N0 + cx * N2, fy * N1 + cy * N2) * s;
+    const float C2 = fmaxf(fx * fabsf(pc.tx) + cx * fabsf(pc.tz), fy * fabsf(pc.ty) + cy * fabsf(pc.tz)) * s;
+    const float mc = fminf(cx, cy);
+    // every magnitude the chain can produce stays far inside the float range (rho itself is inside [2^-40, 2^41) or the
+    // lane is slow anyway): no overflow, no denormal reciprocal
+    const bool sane = (C1 < 0x1p60f) & (C2 < 0x1p60f) & (mc >= 1.0f) & (mc < 0x1p30f) & (fx < 0x1p30f) & (fy < 0x1p30f);
+    pc.pb[0] = sane ? 8.0f * d * C1 * s : __builtin_inff();  // (a NaN operand fails `sane`)
+    pc.pb[1] = sane ? 4.0f * d * C2 * s : __builtin_inff();
+    pc.pb[2] = sane ? 0.3125f / mc * s : __builtin_inff();
+}
+
 // ---- per-batch constant tables ----------------------------------------------------------------------
 // One thread per (reference, neighbour): the host work of PM.cc:170-195 (F12, R21, t21) done on
 // device from the resident keyframe metadata, so a batch needs only slot indices from the host.
@@ -88,7 +123,7 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
                              const int* __restrict__ nbr_slots, const float* __restrict__ rot,
                              const float* __restrict__ mind, const float* __restrict__ maxd,
                              const int* __restrict__ act_counts, const int* __restrict__ theta_bad, int n_ref, int n,
-                             RefConst* __restrict__ refs, PairConst* __restrict__ pairs)
+                             int W, int H, RefConst* __restrict__ refs, PairConst* __restrict__ pairs)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_ref * n) return;
@@ -117,7 +152,13 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     // in [-360,360]: the closed-form gates of the scan hold for every candidate of this pair (sdm_device.h)
     pc.clean = ((theta_bad[ref_slots[r]] == 0 && theta_bad[nbr_slots[idx]] == 0 && pc.rot >= -360.0f && pc.rot <= 360.0f) ? 1 : 0) |
                (line_quot_safe(pc.F) ? 2 : 0);
-    pc.pad[0] = pc.pad[1] = pc.pad[2] = 0.f;
+    // K4's approximate projection (k4_proj_bounds): the largest |xp0|, |xp1| any pixel of the reference image can have
+    {
+        const float s = 1.0f + 0x1p-20f;
+        const float X0 = fmaxf(fabsf(m1.cx), fabsf((float)(W - 1) - m1.cx)) / fabsf(m1.fx) * s;
+        const float X1 = fmaxf(fabsf(m1.cy), fabsf((float)(H - 1) - m1.cy)) / fabsf(m1.fy) * s;
+        k4_proj_bounds(pc, X0, X1);
+    }
     pairs[idx] = pc;
     if (j == 0) {
         RefConst rc;
@@ -994,16 +1035,17 @@ struct __attribute__((packed, aligned(8))) Row2 {  // {rho,sigma} of two horizon
 // scalar instructions per pixel-neighbour against ~330 vector ones.  So the per-neighbour body is straight-line:
 //   * every quotient takes its reciprocal form unconditionally (Markstein: q = a*r, two FMA residual steps; 1/b as
 //     v_rcp_f32 + one FMA step) -- bit-identical to the IEEE quotient whenever numerator and divisor magnitudes lie
-//     in [2^-40, 2^41) and the divisor's significand is not all ones (sdm_selftest(5)/(6));
+//     in [2^-40, 2^41) (sdm_selftest(5)/(6); divisors with an all-ones significand included: round 4 dropped the
+//     detector rounds 1-3 carried for them, tools/ubench/exact_ops.hip);
 //   * instead of guarding each quotient, the running min/max of the operand magnitudes (as integers, so NaN and
-//     Inf land above the window) and an all-ones detector are folded in with v_min3/v_max3;
+//     Inf land above the window) are folded in with v_min3/v_max3;
 //   * the four taps are predicated (operands of a tap that does not count are replaced by 1.0f, its terms are not
 //     added); the 3.84 test is two multiplications and two comparisons, and a tap whose statistic is within
 //     2^-13 of 3.84, or whose rho/sigma leave [2^-13, 2^13), raises the same flag;
 //   * ONE test per neighbour: lanes whose flag is set redo that neighbour with the reference statement (plain
 //     divisions, the double tap test).
 struct K4Guard {
-    unsigned hi, lo, ones;  // max / min of |operand| bit patterns; min over divisors of ((bits | ~mant) + 1): 0 = all ones
+    unsigned hi, lo;  // max / min of |operand| bit patterns
 };
 constexpr unsigned K4_MAG_LO = QUOT_MAG_LO, K4_MAG_HI = QUOT_MAG_HI;  // the quotient window (sdm_device.h)
 constexpr unsigned K4_TAP_LO = 114u << 23;          // 2^-13
@@ -1015,10 +1057,6 @@ __device__ __forceinline__ void guard2(K4Guard& g, float a, float b)
     const unsigned ua = absbits(a), ub = absbits(b);
     g.hi = umax3(g.hi, ua, ub);
     g.lo = umin3(g.lo, ua, ub);
-}
-__device__ __forceinline__ void guard_divisor(K4Guard& g, float b)
-{
-    g.ones = min(g.ones, (__float_as_uint(b) | 0xFF800000u) + 1u);
 }
 // the reference statement for one neighbour (PM.cc:677-755, 777-783), given the rows already fetched when the
 // projection agreed (ra/rb are re-read here because an inexact fast projection may have addressed another pixel)
@@ -1074,6 +1112,7 @@ struct K4Proj {
     bool valid;
     float depthj, rzxp;
     K4Guard g;
+    float xj, yj;  // (read by sdm_selftest(7) only)
 };
 struct K4Rows {
     Row2 ra, rb;  // rows y0 and y0 + 1, columns x0 and x0 + 1
@@ -1090,7 +1129,6 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
     const float t1 = quot_fast(n1, depthp, dp) + pc->ty;
     const float t2 = quot_fast(rzxp, depthp, dp) + pc->tz;
     guard2(g, rzxp, t2);
-    guard_divisor(g, t2);
     const float u = pc->nfx * t0 + pc->ncx * t2;  // PM.cc:679
     const float v = pc->nfy * t1 + pc->ncy * t2;
     guard2(g, u, v);
@@ -1109,6 +1147,47 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
     const unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
     P.off = P.valid ? off : 0u;
     P.rzxp = rzxp;
+    P.xj = xj;
+    P.yj = yj;
+    P.g = g;
+    return P;
+}
+// The same projection from the APPROXIMATE chain (see k4_proj_bounds): cell, validity and offset are the exact chain's
+// unless *near is set (then the caller takes inter_project).  No quotient is formed here, so of the operand guards only
+// rzxp's remains (it is the numerator of the taps' J).
+#ifndef SDM_K4_APPROX
+#define SDM_K4_APPROX 1
+#endif
+__device__ __forceinline__ K4Proj inter_project_approx(const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1,
+                                                       float xp0, float xp1, float depthp, float dp, const K4Guard& g0,
+                                                       bool* near)
+{
+    K4Proj P;
+    const float n0 = row_dot_xp(pc->Rx, xp0, xp1), n1 = row_dot_xp(pc->Ry, xp0, xp1);
+    const float rzxp = row_dot_xp(pc->Rz, xp0, xp1);
+    const float t0 = __builtin_fmaf(n0, dp, pc->tx), t1 = __builtin_fmaf(n1, dp, pc->ty), t2 = __builtin_fmaf(rzxp, dp, pc->tz);
+    const float u = pc->nfx * t0 + pc->ncx * t2;
+    const float v = pc->nfy * t1 + pc->ncy * t2;
+    const float r2 = __builtin_amdgcn_rcpf(t2);
+    const float xj = u * r2, yj = v * r2;
+    const float Hh = __builtin_fmaf(pc->pb[0], dp, pc->pb[1]) * fabsf(r2);
+    const float Gg = __builtin_fmaf(Hh, pc->pb[2], 3.0f * 0x1p-23f);
+    const float ex = __builtin_fmaf(Gg, fabsf(xj), Hh), ey = __builtin_fmaf(Gg, fabsf(yj), Hh);
+    // not "clearly inside one integer cell": within the bound of an integer, NaN anywhere, or too large to have a fraction
+    *near = !(fabsf(xj - __builtin_rintf(xj)) > ex) | !(fabsf(yj - __builtin_rintf(yj)) > ey);
+    const float denom2 = depthp * pc->tz;
+    P.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    const unsigned bx = __float_as_uint(xj + 0.0f), by = __float_as_uint(yj + 0.0f);
+    P.valid = (bx < __float_as_uint(colsm1)) & (by < __float_as_uint(rowsm1));
+    const unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
+    P.off = P.valid ? off : 0u;
+    P.rzxp = rzxp;
+    P.xj = xj;
+    P.yj = yj;
+    K4Guard g = g0;
+    const unsigned uz = absbits(rzxp);
+    g.hi = max(g.hi, uz);
+    g.lo = min(g.lo, uz);
     P.g = g;
     return P;
 }
@@ -1134,10 +1213,9 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
     float njf = 0.0f;
     unsigned amb = 0;
     // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
-    // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator and the
-    // all-ones significand of d2sigma are tracked besides.
+    // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator is tracked besides.
     unsigned t_hi = K4_TAP_LO, t_lo = K4_TAP_LO;
-    float rn[4], d2s[4];
+    float rn[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const bool cand = hr[k] > lim;
@@ -1162,7 +1240,6 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
         rnum = c ? rnum : 1.0f;
         const float r0 = quot_fast(rnum, d2sigma, rd);
         rn[k] = rnum;
-        d2s[k] = d2sigma;
         // a tap that does not count adds (finite) * 0 = +-0 to sums that are never -0 (they start at +0): the sums are the
         // reference's, and one select (the 0/1 weight) replaces three.  Finite: its operands are 1.0f or inside the tap
         // window, so |J| <= |rzxp| 2^39 and |r0| <= 2^39, and |rzxp| < 2^20 is part of the slow flag below.
@@ -1174,9 +1251,7 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
     const int nj = (njf > 0.0f) ? 1 : 0;
     guard2(g, rn[0], rn[1]);
     guard2(g, rn[2], rn[3]);
-    g.ones = umin3(g.ones, (__float_as_uint(d2s[0]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[1]) | 0xFF800000u) + 1u);
-    g.ones = umin3(g.ones, (__float_as_uint(d2s[2]) | 0xFF800000u) + 1u, (__float_as_uint(d2s[3]) | 0xFF800000u) + 1u);
-    *slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (g.ones == 0u) | (amb != 0u) | (t_lo < K4_TAP_LO) |
+    *slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (amb != 0u) | (t_lo < K4_TAP_LO) |
             (t_hi > K4_TAP_HI) | (absbits(rzxp) >= 0x49800000u /* 2^20 */);
     return K4Sums{in.kf_count + nj, nsJr, nsJJ};  // PM.cc:755
 }
@@ -1185,7 +1260,13 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
                                                        float depthp, float dp, const K4Guard& g0, K4Sums in,
                                                        bool* slow)
 {
+#if SDM_K4_APPROX
+    bool near;
+    K4Proj P = inter_project_approx(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0, &near);
+    if (__builtin_expect(near, 0)) P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+#else
     const K4Proj P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+#endif
     const K4Rows R = inter_fetch(nb, W, P.off);
     return inter_taps(pc, P, R, dp, in, slow);
 }
@@ -1202,8 +1283,7 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     const float xp0 = ((float)x - rc.cx) / rc.fx, xp1 = ((float)y - rc.cy) / rc.fy;  // PM.cc:677
     const float dp = rcp_exact(depthp);                                                 // PM.cc:769
     // depthp is a divisor of every neighbour's three quotients: its checks are loop invariant
-    K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
-    guard_divisor(g0, depthp);
+    K4Guard g0 = {absbits(depthp), absbits(depthp)};
     K4Sums acc = {0, 0.f, 0.f};
 #if SDM_K4_PIPE
     K4Proj P = inter_project(pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
@@ -1539,13 +1619,13 @@ __device__ __forceinline__ float st_logmag(unsigned& s, float lo_exp, float hi_e
 }
 __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __restrict__ patches,
                                                        PairConst* __restrict__ pcs, unsigned long long* __restrict__ bad,
-                                                       unsigned long long* __restrict__ accepted)
+                                                       unsigned long long* __restrict__ accepted, int report_projections)
 {
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     unsigned s = 0x9E3779B9u * (gid + 1);
     float2* nb = patches + (long long)gid * 6;  // a private 3x2 map (W = 3): rows y0, y0+1 at x0 = 0 or 1
     PairConst* pc = pcs + gid;
-    unsigned long long nbad = 0, nacc = 0;
+    unsigned long long nbad = 0, nacc = 0, nchk = 0;
     for (int it = 0; it < iters; it++) {
         const unsigned mode = xs32(s) & 7u;
         // geometry: near-identity rotation rows, small translation, pixel-scale intrinsics; sometimes wild
@@ -1560,9 +1640,16 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
         if (mode == 1) pc->tz = 0.0f;
         pc->nfx = 1.0f + st_uniform(s);
         pc->nfy = 1.0f + st_uniform(s);
-        pc->ncx = 0.5f + st_uniform(s);
-        pc->ncy = 0.5f + st_uniform(s);
+        pc->ncx = 0.75f + st_uniform(s);  // (below 1 the approximate projection is switched off for the pair)
+        pc->ncy = 0.75f + st_uniform(s);
+        if (mode == 5) {  // pixel-scale intrinsics: coordinates in the hundreds (mostly outside the 3x2 map)
+            pc->nfx *= 400.0f;
+            pc->nfy *= 400.0f;
+            pc->ncx *= 300.0f;
+            pc->ncy *= 200.0f;
+        }
         const float xp0 = (st_uniform(s) - 0.5f) * 0.6f, xp1 = (st_uniform(s) - 0.5f) * 0.6f;
+        k4_proj_bounds(*pc, 0.3f, 0.3f);
         float depthp = (mode == 2) ? st_logmag(s, -60.f, 60.f) : st_logmag(s, -4.f, 4.f);
         if (mode == 3) depthp = __uint_as_float((__float_as_uint(depthp) | 0x7FFFFFu));  // significand all ones
         const float dp = rcp_exact(depthp);
@@ -1588,8 +1675,22 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
             nb[k] = make_float2(rho, sg);
         }
         __threadfence_block();
-        K4Guard g0 = {absbits(depthp), absbits(depthp), 1u};
-        guard_divisor(g0, depthp);
+        K4Guard g0 = {absbits(depthp), absbits(depthp)};
+        {  // the approximate projection, where it does not ask for the exact one, names the exact chain's cell and validity
+            bool near;
+            const K4Proj Pa = inter_project_approx(pc, 3, 2.0f, 1.0f, xp0, xp1, depthp, dp, g0, &near);
+            const float e0 = row_dot_xp(pc->Rx, xp0, xp1) / depthp + pc->tx, e1 = row_dot_xp(pc->Ry, xp0, xp1) / depthp + pc->ty;
+            const float e2 = rz / depthp + pc->tz;
+            const float xe = (pc->nfx * e0 + pc->ncx * e2) / e2, ye = (pc->nfy * e1 + pc->ncy * e2) / e2;
+            const bool ve = xe >= 0 && xe < 2.0f && ye >= 0 && ye < 1.0f;
+            const bool window = (g0.lo >= K4_MAG_LO) & (g0.hi <= K4_MAG_HI);  // rho outside it is slow whatever the projection says
+            if (!near && window) {
+                nchk++;
+                const bool same = ve == Pa.valid && floorf(xe) == floorf(Pa.xj) && floorf(ye) == floorf(Pa.yj) &&
+                                  (!ve || Pa.off == (((unsigned)(int)floorf(ye) * 3u + (unsigned)(int)floorf(xe)) << 3));
+                if (!same) nbad++;
+            }
+        }
         const K4Sums in = {(int)(xs32(s) & 3u), (st_uniform(s) - 0.5f) * 10.f, st_uniform(s) * 10.f};
         bool slow;
         // W = 3, H = 2: valid projections have 0 <= xj < 2, 0 <= yj < 1
@@ -1606,10 +1707,11 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_k4(int iters, float2* __rest
     for (int o = 32; o > 0; o >>= 1) {
         nbad += __shfl_down(nbad, o);
         nacc += __shfl_down(nacc, o);
+        nchk += __shfl_down(nchk, o);
     }
     if ((threadIdx.x & 63) == 0) {
         if (nbad) atomicAdd(bad, nbad);
-        atomicAdd(accepted, nacc);
+        atomicAdd(accepted, report_projections ? nchk : nacc);  // which = 9: projections decided by the approximate chain
     }
 }
 

@@ -51,7 +51,8 @@ def test_fusion_terms_shared_reciprocal(pkg, gpu_ok):
 
 def test_shared_divisor_quotient(pkg, gpu_ok):
     """a/b as a*r with two FMA corrections, r = v_rcp_f32 + one FMA step (K4's quot_fast / rcp_fast) == IEEE division
-    for every operand pair inside the quotient window [2^-40, 2^41), divisor significand not all ones"""
+    for every operand pair inside the quotient window [2^-40, 2^41), all-ones divisor significands included; and for the
+    operands K1's line quotients see (zero or [2^-59, 2^38], b != 0)"""
     eng = pkg.Engine(64, 48, 2)
     bad, tested = eng.selftest(5)
     assert bad == 0
@@ -60,7 +61,8 @@ def test_shared_divisor_quotient(pkg, gpu_ok):
 
 
 def test_exact_reciprocal(pkg, gpu_ok):
-    """v_rcp_f32 + one FMA residual step == IEEE 1.0f/b for every float bit pattern (guards route the rest)"""
+    """v_rcp_f32 + one FMA residual step == IEEE 1.0f/b for every float bit pattern (guards route the rest); the same walk
+    checks sqrt_exact (v_rsq_f32 + one FMA step inside [2^-100, 2^127), sqrtf outside) against sqrtf"""
     eng = pkg.Engine(64, 48, 2)
     bad, fast = eng.selftest(6)
     assert bad == 0
@@ -77,6 +79,18 @@ def test_inter_check_fast_body_vs_reference_statement(pkg, gpu_ok):
     assert bad == 0
     total = 1024 * 256 * 2048
     assert 0.25 * total < accepted <= total, accepted  # the fast path is the common case, and it is really exercised
+    eng.close()
+
+
+def test_inter_check_approximate_projection(pkg, gpu_ok):
+    """K4's approximate projection (one FMA per row instead of a quotient, v_rcp_f32 instead of the two divisions by z):
+    wherever it does not ask for the exact chain, cell, validity and offset are the plain-division chain's -- the same
+    5*10^8 random geometries as selftest 7, incl. pixel-scale intrinsics; and it decides the common case"""
+    eng = pkg.Engine(64, 48, 2)
+    bad, decided = eng.selftest(9)
+    assert bad == 0
+    total = 1024 * 256 * 2048
+    assert 0.5 * total < decided <= total, decided
     eng.close()
 
 
