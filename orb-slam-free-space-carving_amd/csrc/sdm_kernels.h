@@ -1158,6 +1158,12 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #ifndef SDM_K4_APPROX
 #define SDM_K4_APPROX 1
 #endif
+#ifndef SDM_K4_TAPABS
+#define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
+#endif
+#ifndef SDM_K4_CPRE
+#define SDM_K4_CPRE 0  // 1: the next neighbour's constant block is requested (scalar loads) before this neighbour is evaluated
+#endif
 __device__ __forceinline__ K4Proj inter_project_approx(const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1,
                                                        float xp0, float xp1, float depthp, float dp, const K4Guard& g0,
                                                        bool* near)
@@ -1191,6 +1197,18 @@ __device__ __forceinline__ K4Proj inter_project_approx(const PairConst* __restri
     P.g = g;
     return P;
 }
+__device__ __forceinline__ K4Proj inter_project_any(const PairConst* __restrict__ pc, int W, float colsm1, float rowsm1,
+                                                    float xp0, float xp1, float depthp, float dp, const K4Guard& g0)
+{
+#if SDM_K4_APPROX
+    bool near;
+    K4Proj P = inter_project_approx(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0, &near);
+    if (__builtin_expect(near, 0)) P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+    return P;
+#else
+    return inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+#endif
+}
 __device__ __forceinline__ K4Rows inter_fetch(const float2* __restrict__ nb, int W, unsigned off)
 {
     const char* __restrict__ nbb = reinterpret_cast<const char*>(nb);
@@ -1220,7 +1238,13 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
     for (int k = 0; k < 4; k++) {
         const bool cand = hr[k] > lim;
         const float hx = cand ? hr[k] : 1.0f, sg = cand ? hs[k] : 1.0f;  // harmless operands otherwise
+        // (no |.|: a candidate's rho_n is positive, and a negative sigma_n -- never produced by the pipeline -- has its sign
+        // bit set: above the window as an unsigned number, so the lane takes the reference statement)
+#if SDM_K4_TAPABS
         const unsigned uh = absbits(hx), us = absbits(sg);
+#else
+        const unsigned uh = __float_as_uint(hx), us = __float_as_uint(sg);
+#endif
         t_hi = umax3(t_hi, uh, us);
         t_lo = umin3(t_lo, uh, us);
         // "test < 3.84" (PM.cc:709-710) without a division: with sigma in the window, dd^2 < 3.8397 sigma^2 and
@@ -1260,13 +1284,7 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
                                                        float depthp, float dp, const K4Guard& g0, K4Sums in,
                                                        bool* slow)
 {
-#if SDM_K4_APPROX
-    bool near;
-    K4Proj P = inter_project_approx(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0, &near);
-    if (__builtin_expect(near, 0)) P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
-#else
-    const K4Proj P = inter_project(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
-#endif
+    const K4Proj P = inter_project_any(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
     const K4Rows R = inter_fetch(nb, W, P.off);
     return inter_taps(pc, P, R, dp, in, slow);
 }
@@ -1286,14 +1304,14 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
     K4Guard g0 = {absbits(depthp), absbits(depthp)};
     K4Sums acc = {0, 0.f, 0.f};
 #if SDM_K4_PIPE
-    K4Proj P = inter_project(pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+    K4Proj P = inter_project_any(pcs, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
     K4Rows R = inter_fetch(pool + (long long)pcs->nbr_slot * plane, W, P.off);
     for (int j = 0; j < n; j++) {
         const PairConst* __restrict__ pc = pcs + j;
         const float2* __restrict__ nb = pool + (long long)pc->nbr_slot * plane;
         // the next neighbour's rows are requested before this one's are consumed (the last round repeats its own: in cache)
         const PairConst* __restrict__ pcn = pcs + min(j + 1, n - 1);
-        const K4Proj Pn = inter_project(pcn, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
+        const K4Proj Pn = inter_project_any(pcn, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
         const K4Rows Rn = inter_fetch(pool + (long long)pcn->nbr_slot * plane, W, Pn.off);
         bool slow;
         const K4Sums fast = inter_taps(pc, P, R, dp, acc, &slow);
@@ -1303,6 +1321,20 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
             acc = fast;
         P = Pn;
         R = Rn;
+    }
+#else
+#if SDM_K4_CPRE
+    PairConst nxt = pcs[0];
+    for (int j = 0; j < n; j++) {
+        const PairConst cur = nxt;
+        if (j + 1 < n) nxt = pcs[j + 1];
+        const float2* __restrict__ nb = pool + (long long)cur.nbr_slot * plane;
+        bool slow;
+        const K4Sums fast = inter_neighbour_fast(nb, &cur, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0, acc, &slow);
+        if (__builtin_expect(slow, 0))
+            acc = inter_neighbour_exact(nb, pcs + j, W, colsm1, rowsm1, xp0, xp1, depthp, dp, acc);
+        else
+            acc = fast;
     }
 #else
     for (int j = 0; j < n; j++) {
@@ -1315,6 +1347,7 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
         else
             acc = fast;
     }
+#endif
 #endif
     if (acc.kf_count < lambdaN) return 0.0f;      // PM.cc:764
     float dpDelta = (-acc.sum_Jr) / acc.sum_JJ;   // PM.cc:788-791
