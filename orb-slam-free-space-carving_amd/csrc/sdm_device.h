@@ -338,6 +338,23 @@ struct SearchStats {
     unsigned long long searches, candidates, gate_pass;
 };
 
+// ---- correctly rounded reciprocal --------------------------------------------------------------------------
+// 1.0f/b as v_rcp_f32 (<= 1 ulp) plus one FMA residual step.  On gfx950 this is bit-identical to the
+// IEEE quotient for EVERY b with 2^-125 <= |b| < 2^125 (sdm_selftest(6) walks all 2^32 bit patterns);
+// zero, denormal, huge, Inf and NaN operands take the plain division.  ~2.3x cheaper than the
+// v_div_scale/v_div_fmas/v_div_fixup sequence (tools/ubench/rcp.hip).
+__device__ __forceinline__ float rcp_exact(float b)
+{
+    const float ab = fabsf(b);
+    if (__builtin_expect(!((ab >= 0x1p-125f) & (ab < 0x1p125f)), 0)) return 1.0f / b;
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+#ifndef SDM_K1_OPT_ATAN_RCP
+#define SDM_K1_OPT_ATAN_RCP 1  // the steep-line branch's 1/|y| through rcp_exact
+#endif
 // cv::fastAtan2(y, 1.0f) (PM.cc:414): fast_atan2_deg specialised for x == 1.  With ax = 1 the
 // first branch divides by 1.0f + (float)DBL_EPSILON == 1.0f, i.e. c == ay exactly, so the common
 // |a/b| <= 1 case needs no division; results are bit-identical to fast_atan2_deg(y, 1.0f).
@@ -355,7 +372,11 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
         c2 = c * c;
         a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     } else {
+#if SDM_K1_OPT_ATAN_RCP
+        c = rcp_exact(ay + (float)DBL_EPSILON);  // == 1.0f / (...) for every operand (sdm_selftest(6))
+#else
         c = 1.0f / (ay + (float)DBL_EPSILON);
+#endif
         c2 = c * c;
         a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
@@ -387,8 +408,9 @@ __device__ __forceinline__ float fast_atan2_deg_x1(float y)
 //        whose F12 entries are +0 or of moderate magnitude (PairConst::clean bit 1, line_quot_safe): no per-lane guard
 // bit 16 sqrtf(ustar_var) (PM.cc:818) as v_rsq_f32 + one FMA residual step, exact for every x in [2^-100, 2^127)
 //        (tools/ubench/exact_ops.hip walks all positive floats; sdm_selftest(6) repeats it)
+// bit 17 the refinement's two records as one 16-byte gather each
 #ifndef SDM_K1_OPT
-#define SDM_K1_OPT 0x1a27f
+#define SDM_K1_OPT 0x3a27f
 #endif
 
 // what one search reads of its PairConst, as float indices into the block `cv` points at: the PairConst itself
@@ -879,8 +901,17 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
     if (!(fyp >= 0.0f && fyp <= hlim2)) return false;
     if (!(fym >= 0.0f && fym <= hlim2)) return false;
     int y0p = (int)fyp, y0m = (int)fym;
+#if SDM_K1_OPT & 0x20000
+    // one 16-byte gather per record (hipcc otherwise splits each into a 4-byte and an 8-byte load: .y is not used here)
+    v4f vp = *reinterpret_cast<const v4f*>(nbase + ((__umul24((unsigned)y0p, (unsigned)W) + (unsigned)up) << 4));
+    v4f vm = *reinterpret_cast<const v4f*>(nbase + ((__umul24((unsigned)y0m, (unsigned)W) + (unsigned)um) << 4));
+    asm volatile("" : "+v"(vp));
+    asm volatile("" : "+v"(vm));
+    const float4 rp = make_float4(vp.x, vp.y, vp.z, vp.w), rm = make_float4(vm.x, vm.y, vm.z, vm.w);
+#else
     float4 rp = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0p, (unsigned)W) + (unsigned)up) << 4));
     float4 rm = *reinterpret_cast<const float4*>(nbase + ((__umul24((unsigned)y0m, (unsigned)W) + (unsigned)um) << 4));
+#endif
     const float y1p = fyp + 1.0f, y1m = fym + 1.0f;
     float g = (rec_lerp_im(rp, y1p, yfp) - rec_lerp_im(rm, y1m, yfm)) / 2;      // PM.cc:452
     float q = (rec_lerp_grad(rp, y1p, yfp) - rec_lerp_grad(rm, y1m, yfm)) / 2;  // PM.cc:453
@@ -971,20 +1002,6 @@ __device__ __forceinline__ void fusion_accum(float rho, float sg, float& pjsj, f
 // it, so the double comparison of a widened float is this float comparison (NaN: false both ways).
 __device__ __forceinline__ bool gt_1em6(float x) { return x > __uint_as_float(0x358637bdu); }
 __device__ __forceinline__ bool lt_1em6(float x) { return x <= __uint_as_float(0x358637bdu); }
-
-// ---- correctly rounded reciprocal --------------------------------------------------------------------------
-// 1.0f/b as v_rcp_f32 (<= 1 ulp) plus one FMA residual step.  On gfx950 this is bit-identical to the
-// IEEE quotient for EVERY b with 2^-125 <= |b| < 2^125 (sdm_selftest(6) walks all 2^32 bit patterns);
-// zero, denormal, huge, Inf and NaN operands take the plain division.  ~2.3x cheaper than the
-// v_div_scale/v_div_fmas/v_div_fixup sequence (tools/ubench/rcp.hip).
-__device__ __forceinline__ float rcp_exact(float b)
-{
-    const float ab = fabsf(b);
-    if (__builtin_expect(!((ab >= 0x1p-125f) & (ab < 0x1p125f)), 0)) return 1.0f / b;
-    const float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
 
 // InverseDepthHypothesisFusion PM.cc:598-626 over a thread-private column hyp[i*stride], i < nh.
 //
