@@ -1110,7 +1110,7 @@ __device__ __noinline__ K4Sums inter_neighbour_exact(const float2* __restrict__ 
 struct K4Proj {
     unsigned off;  // byte offset of pixel (y0, x0) inside the neighbour's map (0 when the projection falls outside)
     bool valid;
-    float depthj, rzxp;
+    float den, rzxp;  // den = rzxp + rho tz: rho_j = rho / den (PM.cc:684-688), formed by inter_taps
     K4Guard g;
     float xj, yj;  // (read by sdm_selftest(7) only)
 };
@@ -1135,7 +1135,7 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
     const float r2 = rcp_fast(t2);
     const float xj = quot_fast(u, t2, r2), yj = quot_fast(v, t2, r2);  // PM.cc:680
     const float denom2 = depthp * pc->tz;
-    P.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    P.den = rzxp + denom2;
     // PM.cc:695: 0 <= xj < cols-1 and 0 <= yj < rows-1 as ONE unsigned comparison per coordinate: x + 0.0f turns a -0
     // (which passes "x >= 0") into +0, a non-negative float orders like its bit pattern, negative values and NaN land
     // above every bound
@@ -1161,6 +1161,12 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #ifndef SDM_K4_TAPABS
 #define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
 #endif
+#ifndef SDM_K4_NBRSKIP
+#define SDM_K4_NBRSKIP 0  // 1: a neighbour in which no lane of the wave has a candidate tap skips the tap block (and rho_j's division)
+#endif
+#ifndef SDM_K4_TAPSKIP
+#define SDM_K4_TAPSKIP 1  // 1: a tap that counts for no lane of the wave skips its Gauss-Newton terms (one ballot per tap)
+#endif
 #ifndef SDM_K4_CPRE
 #define SDM_K4_CPRE 0  // 1: the next neighbour's constant block is requested (scalar loads) before this neighbour is evaluated
 #endif
@@ -1182,7 +1188,7 @@ __device__ __forceinline__ K4Proj inter_project_approx(const PairConst* __restri
     // not "clearly inside one integer cell": within the bound of an integer, NaN anywhere, or too large to have a fraction
     *near = !(fabsf(xj - __builtin_rintf(xj)) > ex) | !(fabsf(yj - __builtin_rintf(yj)) > ey);
     const float denom2 = depthp * pc->tz;
-    P.depthj = depthp / (rzxp + denom2);  // PM.cc:684-688
+    P.den = rzxp + denom2;
     const unsigned bx = __float_as_uint(xj + 0.0f), by = __float_as_uint(yj + 0.0f);
     P.valid = (bx < __float_as_uint(colsm1)) & (by < __float_as_uint(rowsm1));
     const unsigned off = (__umul24((unsigned)cvt_i32_sat(yj), (unsigned)W) + (unsigned)cvt_i32_sat(xj)) << 3;
@@ -1217,12 +1223,12 @@ __device__ __forceinline__ K4Rows inter_fetch(const float2* __restrict__ nb, int
     R.rb = *reinterpret_cast<const Row2*>(nbb + (size_t)W * 8 + off);
     return R;
 }
-__device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, const K4Proj& P, const K4Rows& R, float dp,
-                                             K4Sums in, bool* slow)
+__device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, const K4Proj& P, const K4Rows& R, float depthp,
+                                             float dp, K4Sums in, bool* slow)
 {
     const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
     K4Guard g = P.g;
-    const float rzxp = P.rzxp, depthj = P.depthj;
+    const float rzxp = P.rzxp, depthj = depthp / P.den;  // PM.cc:684-688
     const Row2 ra = R.ra, rb = R.rb;
     const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
     const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
@@ -1256,6 +1262,10 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
         const bool c = dd2 < 3.8397f * s2;
         const bool sure_no = dd2 > 3.8403f * s2;
         amb |= c ? 0u : (sure_no ? 0u : 1u);  // also NaN operands
+#if SDM_K4_TAPSKIP
+        rn[k] = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(c) == 0ull) continue;  // wave-uniform: no lane's tap k counts
+#endif
         const float djn = rcp_fast(hx);  // PM.cc:777-783
         const float d2sigma = djn * djn * sg;
         const float rd = rcp_fast(d2sigma);
@@ -1286,7 +1296,18 @@ __device__ __forceinline__ K4Sums inter_neighbour_fast(const float2* __restrict_
 {
     const K4Proj P = inter_project_any(pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
     const K4Rows R = inter_fetch(nb, W, P.off);
-    return inter_taps(pc, P, R, dp, in, slow);
+#if SDM_K4_NBRSKIP
+    {  // wave-uniform: no lane has a candidate tap (rho_n > 1e-6 at a valid projection, PM.cc:695, 705) in this neighbour --
+       // the reference statement leaves count and sums alone as well, whatever the operand magnitudes
+        const float lim = P.valid ? __uint_as_float(0x358637bdu) : __builtin_inff();
+        const bool anyc = (R.ra.r0 > lim) | (R.rb.r0 > lim) | (R.ra.r1 > lim) | (R.rb.r1 > lim);
+        if (__builtin_amdgcn_ballot_w64(anyc) == 0ull) {
+            *slow = false;
+            return in;
+        }
+    }
+#endif
+    return inter_taps(pc, P, R, depthp, dp, in, slow);
 }
 
 #ifndef SDM_K4_PIPE
@@ -1314,7 +1335,7 @@ __device__ __forceinline__ float inter_check_pixel(const float2* __restrict__ po
         const K4Proj Pn = inter_project_any(pcn, W, colsm1, rowsm1, xp0, xp1, depthp, dp, g0);
         const K4Rows Rn = inter_fetch(pool + (long long)pcn->nbr_slot * plane, W, Pn.off);
         bool slow;
-        const K4Sums fast = inter_taps(pc, P, R, dp, acc, &slow);
+        const K4Sums fast = inter_taps(pc, P, R, depthp, dp, acc, &slow);
         if (__builtin_expect(slow, 0))
             acc = inter_neighbour_exact(nb, pc, W, colsm1, rowsm1, xp0, xp1, depthp, dp, acc);
         else
