@@ -1243,6 +1243,10 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const bool cand = hr[k] > lim;
+#if SDM_K4_TAPSKIP >= 2
+        rn[k] = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;  // wave-uniform: tap k is a candidate for no lane
+#endif
         const float hx = cand ? hr[k] : 1.0f, sg = cand ? hs[k] : 1.0f;  // harmless operands otherwise
         // (no |.|: a candidate's rho_n is positive, and a negative sigma_n -- never produced by the pipeline -- has its sign
         // bit set: above the window as an unsigned number, so the lane takes the reference statement)
