@@ -1161,6 +1161,9 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #ifndef SDM_K4_TAPABS
 #define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
 #endif
+#ifndef SDM_K4_TAPSEL
+#define SDM_K4_TAPSEL 1  // 1: the taps' terms selected at the end instead of weighted; candidate-ness in the lane masks
+#endif
 #ifndef SDM_K4_NBRSKIP
 #define SDM_K4_NBRSKIP 0  // 1: a neighbour in which no lane of the wave has a candidate tap skips the tap block (and rho_j's division)
 #endif
@@ -1234,8 +1237,12 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
     const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
     const float lim = P.valid ? f0 : __builtin_inff();  // rho_n > 1e-6 and the projection is inside
     float nsJr = in.sum_Jr, nsJJ = in.sum_JJ;
+#if SDM_K4_TAPSEL
+    bool anyc = false, ambb = false;
+#else
     float njf = 0.0f;
     unsigned amb = 0;
+#endif
     // candidate taps (rho_n > 1e-6, inside): rho_n and sigma_n must lie in [2^-13, 2^13).  That alone bounds
     // sigma^2, 1/rho_n and d2sigma = sigma/rho_n^2 inside the quotient window, so only r0's numerator is tracked besides.
     unsigned t_hi = K4_TAP_LO, t_lo = K4_TAP_LO;
@@ -1261,6 +1268,34 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
         // dd^2 > 3.8403 sigma^2 (float products, relative error < 2^-22) are certain; in between the exact test
         // decides.  dd^2 = +Inf marks a tap that is not a candidate: never compatible, never ambiguous.
         const float dd = depthj - hr[k];
+#if SDM_K4_TAPSEL
+        // candidate-ness folded into the lane masks (scalar pipe) instead of a select on dd^2; the terms of a tap that does not
+        // count are selected away at the end (no 0/1 weight, no substituted numerator: an incompatible tap whose numerator
+        // leaves the operand window only sends its lane to the reference statement)
+        const float dd2 = dd * dd;
+        const float s2 = sg * sg;
+        const bool c = cand & (dd2 < 3.8397f * s2);
+        const bool sure_no = !cand | (dd2 > 3.8403f * s2);
+        ambb |= !(c | sure_no);  // also NaN operands of a candidate
+#if SDM_K4_TAPSKIP
+        rn[k] = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(c) == 0ull) continue;  // wave-uniform: no lane's tap k counts
+#endif
+        const float djn = rcp_fast(hx);  // PM.cc:777-783
+        const float d2sigma = djn * djn * sg;
+        const float rd = rcp_fast(d2sigma);
+        const float J = quot_fast(-rzxp, d2sigma, rd);      // PM.cc:782
+        const float rnum = djn - dp * rzxp - pc->tz;        // PM.cc:783
+        const float r0 = quot_fast(rnum, d2sigma, rd);
+        rn[k] = rnum;
+        const float sJr = nsJr + J * r0, sJJ = nsJJ + J * J;
+        nsJr = c ? sJr : nsJr;
+        nsJJ = c ? sJJ : nsJJ;
+        anyc |= c;
+    }
+    const int nj = anyc ? 1 : 0;
+    const unsigned amb = ambb ? 1u : 0u;
+#else
         const float dd2 = cand ? dd * dd : __builtin_inff();
         const float s2 = sg * sg;
         const bool c = dd2 < 3.8397f * s2;
@@ -1287,6 +1322,7 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
         njf += wgt;
     }
     const int nj = (njf > 0.0f) ? 1 : 0;
+#endif
     guard2(g, rn[0], rn[1]);
     guard2(g, rn[2], rn[3]);
     *slow = (g.lo < K4_MAG_LO) | (g.hi > K4_MAG_HI) | (amb != 0u) | (t_lo < K4_TAP_LO) |
