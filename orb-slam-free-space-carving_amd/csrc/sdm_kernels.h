@@ -1149,6 +1149,13 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
     P.rzxp = rzxp;
     P.xj = xj;
     P.yj = yj;
+#if SDM_K4_DEPTHJ_QUOT
+    {
+        const unsigned ud = absbits(P.den);
+        g.hi = max(g.hi, ud);
+        g.lo = min(g.lo, ud);
+    }
+#endif
     P.g = g;
     return P;
 }
@@ -1160,6 +1167,9 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #endif
 #ifndef SDM_K4_TAPABS
 #define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
+#endif
+#ifndef SDM_K4_DEPTHJ_QUOT
+#define SDM_K4_DEPTHJ_QUOT 1  // 1: rho_j's quotient in reciprocal form, its divisor in the operand window
 #endif
 #ifndef SDM_K4_TAPSEL
 #define SDM_K4_TAPSEL 1  // 1: the taps' terms selected at the end instead of weighted; candidate-ness in the lane masks
@@ -1201,8 +1211,15 @@ __device__ __forceinline__ K4Proj inter_project_approx(const PairConst* __restri
     P.yj = yj;
     K4Guard g = g0;
     const unsigned uz = absbits(rzxp);
+#if SDM_K4_DEPTHJ_QUOT
+    // rho_j = rho / den in reciprocal form as well: den joins rzxp in the operand window (rho is in it already)
+    const unsigned ud = absbits(P.den);
+    g.hi = umax3(g.hi, uz, ud);
+    g.lo = umin3(g.lo, uz, ud);
+#else
     g.hi = max(g.hi, uz);
     g.lo = min(g.lo, uz);
+#endif
     P.g = g;
     return P;
 }
@@ -1231,7 +1248,11 @@ __device__ __forceinline__ K4Sums inter_taps(const PairConst* __restrict__ pc, c
 {
     const float f0 = __uint_as_float(0x358637bdu);  // largest float below 1e-6 (gt_1em6)
     K4Guard g = P.g;
+#if SDM_K4_DEPTHJ_QUOT
+    const float rzxp = P.rzxp, depthj = quot_fast(depthp, P.den, rcp_fast(P.den));  // PM.cc:684-688; operands in P.g's window
+#else
     const float rzxp = P.rzxp, depthj = depthp / P.den;  // PM.cc:684-688
+#endif
     const Row2 ra = R.ra, rb = R.rb;
     const float hr[4] = {ra.r0, rb.r0, ra.r1, rb.r1};  // (y0,x0),(y1,x0),(y0,x1),(y1,x1): PM.cc:705-741
     const float hs[4] = {ra.s0, rb.s0, ra.s1, rb.s1};
