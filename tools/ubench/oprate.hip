@@ -104,6 +104,25 @@ KERNELS(k_pair_cnd_add, "v_cndmask_b32_e64 %0, %0, %1, s[40:41]\n v_add_f32 %2, 
 KERNEL64(k_pair_f64_add, "v_mul_f64 v[60:61], v[60:61], v[62:63]\n v_add_f32 %2, 1.0, %2\n v_add_f64 v[62:63], v[62:63], v[60:61]\n v_add_f32 %3, 1.0, %3")
 KERNELS(k_pair_sgpr_add, "v_add_f32 %0, s42, %0\n v_add_f32 %2, 1.0, %2\n v_add_f32 %1, s42, %1\n v_add_f32 %3, 1.0, %3")
 
+// packed fp32 (two results per lane and instruction; operands are aligned VGPR pairs): does one v_pk_* issue like one or like two?
+#define KERNELPK(NAME, ASM4)                                                                    \
+    __global__ __launch_bounds__(256) void NAME(float* out, int iters, float seed)             \
+    {                                                                                           \
+        float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x, c = seed * 3, d = seed * 5;   \
+        asm volatile("v_mov_b32 v56, %0\n v_mov_b32 v57, %1\n v_mov_b32 v58, %0\n v_mov_b32 v59, %1\n v_mov_b32 v60, %0\n v_mov_b32 v61, %1\n v_mov_b32 v62, %1\n v_mov_b32 v63, %0" \
+                     : : "v"(a), "v"(b) : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"); \
+        for (int it = 0; it < iters; it++) {                                                    \
+            REP16(asm volatile(ASM4 : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");) \
+        }                                                                                       \
+        asm volatile("v_add_f32 %0, v56, %0\n v_add_f32 %0, v58, %0\n v_add_f32 %0, v60, %0\n v_add_f32 %0, v62, %0" : "+v"(a) : : "v56", "v58", "v60", "v62"); \
+        out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;                                    \
+    }
+KERNELPK(k_pk_fma, "v_pk_fma_f32 v[56:57], v[56:57], v[58:59], v[56:57]\n v_pk_fma_f32 v[58:59], v[58:59], v[60:61], v[58:59]\n v_pk_fma_f32 v[60:61], v[60:61], v[62:63], v[60:61]\n v_pk_fma_f32 v[62:63], v[62:63], v[56:57], v[62:63]")
+KERNELPK(k_pk_mul, "v_pk_mul_f32 v[56:57], v[56:57], v[58:59]\n v_pk_mul_f32 v[58:59], v[58:59], v[60:61]\n v_pk_mul_f32 v[60:61], v[60:61], v[62:63]\n v_pk_mul_f32 v[62:63], v[62:63], v[56:57]")
+KERNELPK(k_pk_add, "v_pk_add_f32 v[56:57], v[56:57], v[58:59]\n v_pk_add_f32 v[58:59], v[58:59], v[60:61]\n v_pk_add_f32 v[60:61], v[60:61], v[62:63]\n v_pk_add_f32 v[62:63], v[62:63], v[56:57]")
+KERNELPK(k_pk_fma_add, "v_pk_fma_f32 v[56:57], v[56:57], v[58:59], v[56:57]\n v_add_f32 %2, 1.0, %2\n v_pk_fma_f32 v[60:61], v[60:61], v[62:63], v[60:61]\n v_add_f32 %3, 1.0, %3")
+KERNELPK(k_pk_fma_cvt, "v_pk_fma_f32 v[56:57], v[56:57], v[58:59], v[56:57]\n v_cvt_f32_i32 %2, %2\n v_pk_fma_f32 v[60:61], v[60:61], v[62:63], v[60:61]\n v_cvt_f32_i32 %3, %3")
+
 typedef void (*kern_t)(float*, int, float);
 double run(kern_t k, int blocks, int iters, float* d_out)
 {
@@ -143,7 +162,9 @@ int main(int argc, char** argv)
         {"2 dependent chains, order AABB", k_pair_aabb}, {"2 dependent chains, order ABAB", k_pair_abab},
         {"add->cvt dependent, 2 chains", k_pair_dep_fs}, {"cmp + independent add", k_pair_cmp_add},
         {"cndmask(sgpr mask) + independent add", k_pair_cnd_add}, {"f64 mul/add + independent add", k_pair_f64_add},
-        {"add(sgpr src) + independent add", k_pair_sgpr_add}};
+        {"add(sgpr src) + independent add", k_pair_sgpr_add},
+        {"v_pk_fma_f32 (2 results each)", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul}, {"v_pk_add_f32", k_pk_add},
+        {"pk_fma + independent add (2+2)", k_pk_fma_add}, {"pk_fma + independent cvt (2+2)", k_pk_fma_cvt}};
     // instructions per SIMD: 8 waves * iters * 16 * 4
     const double n_per_simd = (double)wps * iters * 64.0;
     double base = 0;
