@@ -1539,7 +1539,13 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
             for (int r = 0; r < n_ref && fuse; r++) fuse = c->xyz_sparse[ref_slots[r]] != 0;
             if (max_chunks > 0) {
                 max_chunks = (max_chunks * BLOCK + K4_BLOCK - 1) / K4_BLOCK;  // in units of the list kernel's workgroup
-                const int per_ref = 8 * ((max_chunks + 7) / 8);
+                int per_ref = 8 * ((max_chunks + 7) / 8);
+#if SDM_K4_GROUP && SDM_K4_BAND > 0
+                {   // bands of SDM_K4_BAND chunks, dealt to the XCDs round robin: whole bands only
+                    const int cpx = (max_chunks + 7) / 8, band = SDM_K4_BAND < cpx ? SDM_K4_BAND : cpx;
+                    per_ref = 8 * ((cpx + band - 1) / band) * band;
+                }
+#endif
                 for_ref_slices(n_ref, per_ref, K4_BLOCK, [&](int first, int count) {
                     const dim3 grid(per_ref * count);
                     if (fuse)

@@ -1168,6 +1168,13 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #ifndef SDM_K4_TAPABS
 #define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
 #endif
+#ifndef SDM_K4_BAND
+#define SDM_K4_BAND 4  // chunks per band (0: one contiguous band per XCD)
+#endif
+#ifndef SDM_K4_GROUP
+#define SDM_K4_GROUP 8  // n > 0: K4's blocks ordered by image band (per XCD) and groups of n reference keyframes; 0: chunk c of
+                        // every keyframe on XCD c mod 8, reference fastest (rounds 1-3)
+#endif
 #ifndef SDM_K4_DEPTHJ_QUOT
 #define SDM_K4_DEPTHJ_QUOT 1  // 1: rho_j's quotient in reciprocal form, its divisor in the operand window
 #endif
@@ -1521,10 +1528,30 @@ __global__ __launch_bounds__(K4_BLOCK) void k_inter_check_list(const float2* __r
 {
     const int b = blockIdx.x;
     const int i8 = b >> 3;
+#if SDM_K4_GROUP
+    // XCD x (blocks b = x mod 8) walks BANDS of `band` consecutive list chunks -- vertically adjacent chunks of a keyframe read
+    // the same rows of a neighbour's map -- bands dealt to the XCDs round robin, and inside a band groups of SDM_K4_GROUP
+    // consecutive reference keyframes (which share most of their neighbours): reference fastest, then chunk, then group, then
+    // band.  band = chunks per XCD: one contiguous band per XCD.  The host sizes the grid as 8 * n_ref * bands_per_xcd * band.
+    const int cpx = (max_chunks + 7) >> 3;                     // chunks per XCD and keyframe
+    const int band = (SDM_K4_BAND > 0 && SDM_K4_BAND < cpx) ? SDM_K4_BAND : cpx;
+    const int per_band = n_ref * band;                         // blocks of one band on one XCD
+    const int kb = i8 / per_band;
+    const int ib = i8 - kb * per_band;
+    const int per_group = SDM_K4_GROUP * band;
+    const int g = ib / per_group;
+    const int gsz = min(SDM_K4_GROUP, n_ref - g * SDM_K4_GROUP);  // the last group may be short
+    const int tt = ib - g * per_group;
+    const int cc = tt / gsz;
+    const int ref = g * SDM_K4_GROUP + (tt - cc * gsz);
+    const int chunk = (kb * 8 + (b & 7)) * band + cc;
+    if (chunk >= max_chunks) return;
+#else
     const int cl = i8 / n_ref;
     const int ref = i8 - cl * n_ref;
     const int chunk = cl * 8 + (b & 7);
     if (chunk >= max_chunks) return;
+#endif
     const RefConst rc = refs[ref];
     const int t = chunk * K4_BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
