@@ -1343,7 +1343,7 @@ static int run_intra_lists(sdm_ctx* c, int n_ref, const int* ref_slots, bool che
         for (int r = 0; r < count; r++)
             max_chunks = std::max(max_chunks, (c->h_act_count[ref_slots[first + r]] + BLOCK - 1) / BLOCK);
         if (max_chunks == 0) continue;
-        const int per_ref = 8 * ((max_chunks + 7) / 8);
+        const int per_ref = band_grid_per_ref(max_chunks, SDM_K23_GROUP, SDM_K23_BAND);
 #if SDM_INTRA_COMPACT
         // K2 -> compact results (the scratch memory, indexed by list position) -> commit into the pool; K3 = the (normally
         // empty) candidate list K2 collected, grown by one small launch, reads before writes (sdm_kernels.h)
@@ -1539,13 +1539,7 @@ static int inter_check_core(sdm_ctx* c, int n_ref, const int* ref_slots, int n, 
             for (int r = 0; r < n_ref && fuse; r++) fuse = c->xyz_sparse[ref_slots[r]] != 0;
             if (max_chunks > 0) {
                 max_chunks = (max_chunks * BLOCK + K4_BLOCK - 1) / K4_BLOCK;  // in units of the list kernel's workgroup
-                int per_ref = 8 * ((max_chunks + 7) / 8);
-#if SDM_K4_GROUP && SDM_K4_BAND > 0
-                {   // bands of SDM_K4_BAND chunks, dealt to the XCDs round robin: whole bands only
-                    const int cpx = (max_chunks + 7) / 8, band = SDM_K4_BAND < cpx ? SDM_K4_BAND : cpx;
-                    per_ref = 8 * ((cpx + band - 1) / band) * band;
-                }
-#endif
+                const int per_ref = band_grid_per_ref(max_chunks, SDM_K4_GROUP, SDM_K4_BAND);
                 for_ref_slices(n_ref, per_ref, K4_BLOCK, [&](int first, int count) {
                     const dim3 grid(per_ref * count);
                     if (fuse)
@@ -1615,7 +1609,7 @@ int sdm_pointset(sdm_ctx* c, int n_ref, const int* ref_slots, int source)
     }
     if (sparse) {
         if (max_chunks > 0) {
-            const int per_ref = 8 * ((max_chunks + 7) / 8);
+            const int per_ref = band_grid_per_ref(max_chunks, SDM_K23_GROUP, SDM_K23_BAND);
             for_ref_slices(n_ref, per_ref, BLOCK, [&](int first, int count) {
                 hipLaunchKernelGGL(k_pointset_list, dim3(per_ref * count), dim3(BLOCK), 0, c->stream, src, sstride, c->P,
                                    c->d_meta, c->d_refs + first, count, c->W, max_chunks, c->d_act, c->xyz);

@@ -81,6 +81,56 @@ __device__ __forceinline__ int block_compact(const bool (&f)[PX_PER_THREAD], uns
     return total;
 }
 
+#ifndef SDM_K23_GROUP
+#define SDM_K23_GROUP 0  // the same order for the intra-keyframe list kernels (k_intra_compact / _commit / _list)
+#endif
+#ifndef SDM_K23_BAND
+#define SDM_K23_BAND 4
+#endif
+#ifndef SDM_K4_BAND
+#define SDM_K4_BAND 4  // chunks per band (0: one contiguous band per XCD)
+#endif
+#ifndef SDM_K4_GROUP
+#define SDM_K4_GROUP 8  // n > 0: K4's blocks ordered by image band (per XCD) and groups of n reference keyframes; 0: chunk c of
+                        // every keyframe on XCD c mod 8, reference fastest (rounds 1-3)
+#endif
+// ---- block -> (reference keyframe, list chunk) of the list kernels ----------------------------------------------------------
+// Blocks b and b + 8 share an XCD (and its L2).  GROUP == 0: chunk c of EVERY keyframe on XCD c mod 8, reference fastest -- the
+// keyframes that read one region of a neighbour image at the same time share an L2 fill (K1).  GROUP > 0: XCD x takes BANDS of
+// `BAND` consecutive chunks (bands dealt round robin) -- vertically adjacent chunks read the same rows of a map -- and inside a
+// band groups of GROUP consecutive keyframes, reference fastest, then chunk, then group (K2-K4, whose chunk spans an image
+// row).  band_grid_per_ref() is the grid the host launches per keyframe.
+template <int GROUP, int BAND>
+__device__ __forceinline__ bool decode_list_block(int b, int n_ref, int max_chunks, int& ref, int& chunk)
+{
+    const int i8 = b >> 3;
+    if (GROUP == 0) {
+        const int cl = i8 / n_ref;
+        ref = i8 - cl * n_ref;
+        chunk = cl * 8 + (b & 7);
+    } else {
+        const int cpx = (max_chunks + 7) >> 3;  // chunks per XCD and keyframe
+        const int band = (BAND > 0 && BAND < cpx) ? BAND : cpx;
+        const int per_band = n_ref * band;
+        const int kb = i8 / per_band;
+        const int ib = i8 - kb * per_band;
+        const int per_group = GROUP * band;
+        const int g = ib / per_group;
+        const int gsz = min(GROUP, n_ref - g * GROUP);  // the last group may be short
+        const int tt = ib - g * per_group;
+        const int cc = tt / gsz;
+        ref = g * GROUP + (tt - cc * gsz);
+        chunk = (kb * 8 + (b & 7)) * band + cc;
+    }
+    return chunk < max_chunks;
+}
+__host__ __device__ inline int band_grid_per_ref(int max_chunks, int group, int band)
+{
+    const int cpx = (max_chunks + 7) / 8;
+    if (group == 0 || band <= 0 || band >= cpx) return 8 * cpx;
+    return 8 * ((cpx + band - 1) / band) * band;
+}
+
 // ---- K4's approximate projection: per-pair error-bound constants (PairConst::pb) -------------------------------------
 // K4 needs the projection (xj, yj) of PM.cc:677-680 only for the bounds test of PM.cc:695 and floor(): an approximation
 // decides both unless it lies within its error bound of an integer (0 and cols-1 / rows-1 are integers).  With
@@ -862,12 +912,8 @@ __global__ __launch_bounds__(BLOCK) void k_intra_list(const float2* __restrict__
                                                       int max_chunks, long long plane, const unsigned* __restrict__ act,
                                                       const float4* __restrict__ rec, int H, float lambdaG)
 {
-    const int b = blockIdx.x;
-    const int i8 = b >> 3;
-    const int cl = i8 / n_ref;
-    const int r = i8 - cl * n_ref;
-    const int chunk = cl * 8 + (b & 7);
-    if (chunk >= max_chunks) return;
+    int r, chunk;
+    if (!decode_list_block<SDM_K23_GROUP, SDM_K23_BAND>(blockIdx.x, n_ref, max_chunks, r, chunk)) return;
     const RefConst rc = refs[first + r];
     const int t = chunk * BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
@@ -910,12 +956,8 @@ __global__ __launch_bounds__(BLOCK) void k_intra_compact(const float2* __restric
                                                          int max_chunks, long long plane, const unsigned* __restrict__ act,
                                                          GrowList gl)
 {
-    const int b = blockIdx.x;
-    const int i8 = b >> 3;
-    const int cl = i8 / n_ref;
-    const int r = i8 - cl * n_ref;
-    const int chunk = cl * 8 + (b & 7);
-    if (chunk >= max_chunks) return;
+    int r, chunk;
+    if (!decode_list_block<SDM_K23_GROUP, SDM_K23_BAND>(blockIdx.x, n_ref, max_chunks, r, chunk)) return;
     const RefConst rc = refs[first + r];
     const int t = chunk * BLOCK + threadIdx.x;
     const bool on = t < rc.act_count;
@@ -954,12 +996,8 @@ __global__ __launch_bounds__(BLOCK) void k_intra_commit(float2* __restrict__ poo
                                                         const RefConst* __restrict__ refs, int first, int n_ref, int W,
                                                         int max_chunks, long long plane, const unsigned* __restrict__ act)
 {
-    const int b = blockIdx.x;
-    const int i8 = b >> 3;
-    const int cl = i8 / n_ref;
-    const int r = i8 - cl * n_ref;
-    const int chunk = cl * 8 + (b & 7);
-    if (chunk >= max_chunks) return;
+    int r, chunk;
+    if (!decode_list_block<SDM_K23_GROUP, SDM_K23_BAND>(blockIdx.x, n_ref, max_chunks, r, chunk)) return;
     const RefConst rc = refs[first + r];
     const int t = chunk * BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
@@ -1167,13 +1205,6 @@ __device__ __forceinline__ K4Proj inter_project(const PairConst* __restrict__ pc
 #endif
 #ifndef SDM_K4_TAPABS
 #define SDM_K4_TAPABS 0  // 1: |rho_n|, |sigma_n| in the taps' window test (rounds 1-3)
-#endif
-#ifndef SDM_K4_BAND
-#define SDM_K4_BAND 4  // chunks per band (0: one contiguous band per XCD)
-#endif
-#ifndef SDM_K4_GROUP
-#define SDM_K4_GROUP 8  // n > 0: K4's blocks ordered by image band (per XCD) and groups of n reference keyframes; 0: chunk c of
-                        // every keyframe on XCD c mod 8, reference fastest (rounds 1-3)
 #endif
 #ifndef SDM_K4_DEPTHJ_QUOT
 #define SDM_K4_DEPTHJ_QUOT 1  // 1: rho_j's quotient in reciprocal form, its divisor in the operand window
@@ -1526,32 +1557,8 @@ __global__ __launch_bounds__(K4_BLOCK) void k_inter_check_list(const float2* __r
                                                             const unsigned* __restrict__ act, float* __restrict__ chk,
                                                             const KfMeta* __restrict__ meta, float* __restrict__ xyz)
 {
-    const int b = blockIdx.x;
-    const int i8 = b >> 3;
-#if SDM_K4_GROUP
-    // XCD x (blocks b = x mod 8) walks BANDS of `band` consecutive list chunks -- vertically adjacent chunks of a keyframe read
-    // the same rows of a neighbour's map -- bands dealt to the XCDs round robin, and inside a band groups of SDM_K4_GROUP
-    // consecutive reference keyframes (which share most of their neighbours): reference fastest, then chunk, then group, then
-    // band.  band = chunks per XCD: one contiguous band per XCD.  The host sizes the grid as 8 * n_ref * bands_per_xcd * band.
-    const int cpx = (max_chunks + 7) >> 3;                     // chunks per XCD and keyframe
-    const int band = (SDM_K4_BAND > 0 && SDM_K4_BAND < cpx) ? SDM_K4_BAND : cpx;
-    const int per_band = n_ref * band;                         // blocks of one band on one XCD
-    const int kb = i8 / per_band;
-    const int ib = i8 - kb * per_band;
-    const int per_group = SDM_K4_GROUP * band;
-    const int g = ib / per_group;
-    const int gsz = min(SDM_K4_GROUP, n_ref - g * SDM_K4_GROUP);  // the last group may be short
-    const int tt = ib - g * per_group;
-    const int cc = tt / gsz;
-    const int ref = g * SDM_K4_GROUP + (tt - cc * gsz);
-    const int chunk = (kb * 8 + (b & 7)) * band + cc;
-    if (chunk >= max_chunks) return;
-#else
-    const int cl = i8 / n_ref;
-    const int ref = i8 - cl * n_ref;
-    const int chunk = cl * 8 + (b & 7);
-    if (chunk >= max_chunks) return;
-#endif
+    int ref, chunk;
+    if (!decode_list_block<SDM_K4_GROUP, SDM_K4_BAND>(blockIdx.x, n_ref, max_chunks, ref, chunk)) return;
     const RefConst rc = refs[ref];
     const int t = chunk * K4_BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
@@ -1633,12 +1640,8 @@ __global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict
                                                          int max_chunks, const unsigned* __restrict__ act,
                                                          float* __restrict__ xyz)
 {
-    const int b = blockIdx.x;
-    const int i8 = b >> 3;
-    const int cl = i8 / n_ref;
-    const int r = i8 - cl * n_ref;
-    const int chunk = cl * 8 + (b & 7);
-    if (chunk >= max_chunks) return;
+    int r, chunk;
+    if (!decode_list_block<SDM_K23_GROUP, SDM_K23_BAND>(blockIdx.x, n_ref, max_chunks, r, chunk)) return;
     const RefConst rc = refs[r];
     const int t = chunk * BLOCK + threadIdx.x;
     if (t >= rc.act_count) return;
