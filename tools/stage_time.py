@@ -18,9 +18,10 @@ ap.add_argument("--nbrs", type=int, default=20)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--disparity", type=float, default=2.6)
+ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images")
 a = ap.parse_args()
 pkg = sdm_pkg.load()
-wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0)
+wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0, noise=a.noise)
 eng = wl.eng
 for _ in range(3):
     wl.step("halo", "torch")
