@@ -7,7 +7,7 @@ import sdm_pkg  # noqa: E402
 
 pkg = sdm_pkg.load()
 eng = pkg.Engine(64, 48, 2)
-for which in range(8):
+for which in range(10):
     bad, aux = eng.selftest(which)
     print("selftest %d: mismatches %d, aux %d" % (which, bad, aux))
 eng.close()
