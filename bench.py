@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--nbrs", type=int, default=20, help="covisible neighbours per keyframe")
     ap.add_argument("--res", default="480p", choices=["480p", "720p", "1080p"])
     ap.add_argument("--disparity", type=float, default=2.6, help="adjacent-keyframe disparity (px): scan-length knob")
+    ap.add_argument("--prior-spread", type=float, default=0.1,
+                    help="depth prior of StereoSearchConstraints (PM.cc:381-382): s = spread * mu (App. D: 0.1; ORB depths of "
+                         "a real keyframe spread 0.3-0.5) -- the other scan-length knob")
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
@@ -115,7 +118,7 @@ class Workload:
     """One resident workload on this rank: scene, plan, engine, uploaded keyframes."""
 
     def __init__(self, pkg, torch, res, kfs, N, disparity, world, rank, local_rank, independent=False,
-                 keep_images=0, noise=False, outliers=0):
+                 keep_images=0, noise=False, outliers=0, spread=0.1):
         synth, shard = pkg.synth, pkg.shard
         self.pkg, self.torch = pkg, torch
         cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[res]
@@ -133,7 +136,8 @@ class Workload:
         pl = self.pl
         self.outliers = outliers
         n_slots = pl["n_slots"] * (2 if outliers else 1)
-        self.min_d, self.max_d = self.scene.depth_prior()
+        self.spread = spread
+        self.min_d, self.max_d = self.scene.depth_prior(spread)
         # engine on torch's current stream; depth pool owned by torch (the torch transport exchanges it in place)
         self.pool = torch.zeros((n_slots, self.H, self.W, 2), dtype=torch.float32, device="cuda")
         self.eng = pkg.Engine(self.W, self.H, n_slots, max_neighbours=N, device=local_rank,
@@ -274,7 +278,7 @@ def measure(wl, steps, warmup, barrier, exchange, transport, reduce_max=None):
     return dt, timing, dt_c, timing_c, n_pre
 
 
-def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False, outliers=0):
+def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False, outliers=0, spread=0.1):
     """HBM-side bytes of one k_search_fuse launch from a committed PMC run (tools/pmc.sh: rocprofv3 cannot
     run inside bench.py).  Only a file whose workload AND kernel-source hash match this build is used."""
     src = source_hash()
@@ -291,7 +295,8 @@ def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False
         w = t.get("workload", {})
         if t.get("src_hash") == src and \
                 (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity"), bool(w.get("noise", False)),
-                 int(w.get("outliers", 0))) == (res, kfs, nbrs, disparity, bool(noise), int(outliers)):
+                 int(w.get("outliers", 0)), float(w.get("spread", 0.1))) == (res, kfs, nbrs, disparity, bool(noise),
+                                                                             int(outliers), float(spread)):
             return t["traffic_bytes_per_launch"]
     return None
 
@@ -302,17 +307,21 @@ def scan_record(stats, k1_avg_ms):
         "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
         "gate_pass": stats["gate_pass"], "hypotheses": stats["hypotheses"], "fused_pixels": stats["fused"],
         "Mhyp_per_s": round(stats["searches"] / (k1_avg_ms * 1e-3) / 1e6, 1),
+        # how K1 walked the ranges: share of the (wave, neighbour) scans that took the gradient-mask scan
+        "gate_pass_rate": round(stats["gate_pass"] / max(stats["candidates"], 1), 4),
+        "mask_scan_waves": stats.get("mask_waves", 0), "mask_scan_steps": stats.get("mask_steps", 0),
     }
 
 
-def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier, noise=False, outliers=0, tag=None):
+def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier, noise=False, outliers=0, tag=None,
+              spread=0.1):
     """one more single-GPU workload, measured the same way as the headline one (cold and steady state)"""
-    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank, noise=noise, outliers=outliers)
+    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank, noise=noise, outliers=outliers, spread=spread)
     stats = wl.scan_stats()
     dt, timing, dt_c, timing_c, _ = measure(wl, steps, warmup, barrier, "halo", "torch")
-    plain = not (noise or outliers)
+    plain = not (noise or outliers) and spread == 0.1
     rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps,
-                                                               noise=noise, outliers=outliers))
+                                                               noise=noise, outliers=outliers, spread=spread))
     rf_c, _ = roofline(wl, timing_c, steps, None)
     rf["frac_cold"] = rf_c["frac"]
     rf["launch_ms_cold"] = rf_c["launch_ms"]
@@ -323,7 +332,7 @@ def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, bar
         "value": round(wl.P * wl.n_total * steps / dt / 1e6, 2), "unit": "Mpix*KF/s",
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
         "ms_per_step_cold": round(dt_c / steps * 1e3, 4),
-        "keyframes_total": wl.n_total, "neighbours": N, "disparity_px": disparity,
+        "keyframes_total": wl.n_total, "neighbours": N, "disparity_px": disparity, "prior_spread": spread,
         "stage_ms_per_step": {s: round(v[0] / steps, 4) for s, v in timing.items()},
         "roofline": rf,
         "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
@@ -386,6 +395,7 @@ def main():
 
     wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
                   independent=args.independent, noise=args.noise, outliers=(args.outliers if world == 1 else 0),
+                  spread=args.prior_spread,
                   keep_images=max(args.cpu_kfs + 2 * args.nbrs, min(args.kfs, 64)) if (rank == 0 and world == 1) else 0)
     eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
     n_total = wl.n_total * (world if args.independent else 1)
@@ -519,7 +529,7 @@ def main():
     value = P * n_total * args.steps / dt / 1e6
     rf, k1_avg_ms = roofline(wl, timing, args.steps,
                              committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps,
-                                               noise=args.noise, outliers=args.outliers)
+                                               noise=args.noise, outliers=args.outliers, spread=args.prior_spread)
                              if world == 1 else None)
     rf_cold, _ = roofline(wl, timing_cold, args.steps, None)
     rf["frac_cold"] = rf_cold["frac"]  # the same K steps after only the W warm-up steps (no pre-warm phase)
@@ -550,10 +560,12 @@ def main():
         "config": {
             "workload": workload_name(W, H, args.kfs, N, args.res, args.independent) +
                         (", i.i.d. uniform u8 noise images" if args.noise else "") +
+                        (", depth prior s = %g mu" % args.prior_spread if args.prior_spread != 0.1 else "") +
                         (", %d wrong-pose neighbours per keyframe, K1 ONLY stepped (profiling form; `value` is not the "
                          "path's throughput)" % args.outliers if args.outliers else ""),
             "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" % xdesc,
             "keyframes_total": n_total, "neighbours": N, "disparity_px": args.disparity,
+            "prior_spread": args.prior_spread,
             "parallelism": ("independent x%d" if args.independent else "keyframe-block x%d") % world, "arch": arch,
             "exchange": (args.exchange if exchanging else None),
             "transport": (transport if exchanging else None),
@@ -615,7 +627,7 @@ def main():
         out["value_pcie_inclusive_per_keyframe_calls"] = incl(upload_ms["per_keyframe_calls"])
 
     # ---- the other single-GPU BASELINE workloads, each measured like the headline one ----------------------
-    if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs) == ("480p", 64, 20):
+    if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs, args.prior_spread) == ("480p", 64, 20, 0.1):
         wl.close()
         extra = []
         xs = max(5, args.steps // 2)
@@ -626,11 +638,15 @@ def main():
                    dict(res="480p", kfs=64, N=20, disparity=args.disparity, noise=True,
                         tag="configs[1] geometry on i.i.d. uniform u8 images (SURVEY.md §8d adversarial set: scan-only rate)"),
                    dict(res="480p", kfs=64, N=20, disparity=10.0,
-                        tag="configs[1] with a long baseline (adjacent-keyframe disparity 10 px)")):
+                        tag="configs[1] with a long baseline (adjacent-keyframe disparity 10 px)"),
+                   dict(res="480p", kfs=64, N=20, disparity=args.disparity, spread=0.3,
+                        tag="configs[1] with a wide depth prior (s = 0.3 mu, PM.cc:381-382)"),
+                   dict(res="480p", kfs=64, N=20, disparity=10.0, spread=0.3,
+                        tag="configs[1] with a long baseline (10 px) AND a wide depth prior (s = 0.3 mu)")):
             try:
                 extra.append(run_extra(pkg, torch, kw["res"], kw["kfs"], kw["N"], kw["disparity"], xs, 2, local_rank,
                                        barrier, noise=kw.get("noise", False), outliers=kw.get("outliers", 0),
-                                       tag=kw.get("tag")))
+                                       tag=kw.get("tag"), spread=kw.get("spread", 0.1)))
             except Exception as e:  # the headline line must survive a failing extra
                 extra.append({"workload": kw.get("tag") or "%s x %d KF x N=%d" % (kw["res"], kw["kfs"], kw["N"]),
                               "error": repr(e)})

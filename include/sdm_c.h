@@ -64,6 +64,10 @@ typedef struct {
     long long gate_pass;  /* candidates that reached the cost               PM.cc:433 */
     long long hypotheses; /* accepted hypotheses                            PM.cc:216 */
     long long fused;      /* pixels written                                 PM.cc:225 */
+    /* how K1 walked the ranges (not reference quantities): */
+    long long mask_waves; /* (wave, neighbour) scans that took the gradient-mask scan instead of the batched one */
+    long long mask_steps; /* mask words those scans examined (lane steps) */
+    long long mask_row_mismatch; /* self-check of the mask scan's row runs: must stay 0 */
 } sdm_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -293,6 +297,10 @@ float sdm_median_rot_in_plane(const int *mp1, const float *angle1, int n1, const
 /* when enabled, sdm_search_fuse runs its counting variant (slower) and accumulates into stats */
 int sdm_enable_stats(sdm_ctx *ctx, int on);
 int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
+/* diagnostic: how sdm_search_fuse / sdm_recon / sdm_epipolar_search walk the candidate range of PM.cc:405 -- 0 (default): per
+ * wave and neighbour, from the wave's range lengths and line slopes; 1: always the batched scan; 2: always the scan over the
+ * neighbour's gradient-gate bit plane.  Results are the same bit for bit in every mode (tests/test_gpu_longscan.py). */
+int sdm_set_scan_mode(sdm_ctx *ctx, int mode);
 /* per-stage device time measured with HIP events recorded on the context's stream around each
  * stage's kernel launches (K1 = one k_search_fuse launch per sdm_recon/sdm_search_fuse call) */
 #define SDM_STAGE_SEARCH_FUSE 0 /* K1   PM.cc:197-231 */

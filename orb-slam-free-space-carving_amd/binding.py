@@ -29,7 +29,8 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("searches", C.c_longlong), ("candidates", C.c_longlong), ("gate_pass", C.c_longlong),
-                ("hypotheses", C.c_longlong), ("fused", C.c_longlong)]
+                ("hypotheses", C.c_longlong), ("fused", C.c_longlong), ("mask_waves", C.c_longlong),
+                ("mask_steps", C.c_longlong), ("mask_row_mismatch", C.c_longlong)]
 
 
 def lib_path():
@@ -110,6 +111,7 @@ SYMBOLS = [
     ("sdm_median_rot_in_plane", C.c_float, [_ip, _f32p, C.c_int, _ip, _f32p, C.c_int]),
     ("sdm_enable_stats", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_stats", C.c_int, [_ctx, C.POINTER(Stats), C.c_int]),
+    ("sdm_set_scan_mode", C.c_int, [_ctx, C.c_int]),
     ("sdm_selftest", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_ulonglong)]),
     ("sdm_enable_timing", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_timing", C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
@@ -554,6 +556,10 @@ class Engine:
         return F, R, t
 
     # -- instrumentation ---------------------------------------------------------------------------------
+    def set_scan_mode(self, mode):
+        """0 = per wave (default), 1 = batched scan, 2 = gradient-mask scan (diagnostic; results are identical)"""
+        self._check(self.lib.sdm_set_scan_mode(self.ctx, int(mode)))
+
     def enable_stats(self, on=True):
         self._check(self.lib.sdm_enable_stats(self.ctx, 1 if on else 0))
 

@@ -59,6 +59,8 @@ struct DevParams {  // sdm_params + host-precomputed (1/THETA), PM.cc:455-456
     double inv_theta;
     int fast_theta_div;  // x/theta_var via reciprocal + FMA correction (exhaustively verified for 0.23)
     int default_gates;   // lambdaL == 80 && lambdaTheta == 45: the closed-form angle gates apply
+    int scan_mode;       // K1's scan per (wave, neighbour): 0 = chosen from the wave's range lengths and line slopes,
+                         // 1 = always the batched scan, 2 = always the gradient-mask scan (tests; SDM_SCAN_MODE)
 };
 
 // x / d for a double x that was widened from a non-negative float, d = theta_var, r = RN(1/d).
@@ -624,6 +626,69 @@ struct ScanConst {
     float ab, cb, pixel, grad1, th_line, ang_pi_rot, gate_lim;
     int hi;
 };
+// One candidate that passed the row test (PM.cc:408 + N3): the gradient gate, the two angle gates, the matching cost and
+// the arg-min update of PM.cc:411-443.  r = the candidate's record, yf = -((a/b)*uj + c/b) as the reference computes it.
+template <bool STATS, bool CLEAN>
+__device__ __forceinline__ void scan_candidate(const ScanConst& q, int uj, float yf, const float4& r, const DevParams& prm,
+                                               ScanState& S, SearchStats* st)
+{
+    if (r.x < prm.lambdaG) return;                              // PM.cc:411
+#if SDM_ABLATE == 4
+    if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+    return;
+#endif
+    const float d2 = r.y - q.th_line;     // PM.cc:415-416
+    const float d3 = r.y - q.ang_pi_rot;  // PM.cc:427
+#if SDM_K1_OPT & 0x04
+    bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
+#else
+    bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+#endif
+    if (!CLEAN) {
+        if (__builtin_expect(!((d2 < q.gate_lim) & (d3 < q.gate_lim)), 0))
+            fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
+    }
+    if (fail) return;  // PM.cc:421,431
+    if (STATS) st->gate_pass++;
+#if SDM_ABLATE == 3 || SDM_ABLATE == 4
+    if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
+    return;
+#endif
+    const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
+    float pe = q.pixel - rec_lerp_im_w(r, y0w);        // PM.cc:433
+    float ge = q.grad1 - rec_lerp_grad_w(r, y0w);      // PM.cc:434
+#if SDM_K1_OPT & 0x2000
+    if (CLEAN) {  // (this instantiation also implies theta_var == 0.23)
+        // S.old_err holds the APPROXIMATE cost of the best candidate so far (1e6 exactly before the first)
+        const float e = match_cost_approx(pe * pe, ge * ge);
+        bool better = e < S.old_err;
+        if (__builtin_expect((__float_as_uint(e) - __float_as_uint(S.old_err) + COST_BAND) <= 2u * COST_BAND, 0))
+            better = match_cost_ref(pe * pe, ge * ge, prm) < match_cost_ref(S.best_pe * S.best_pe, S.best_ge * S.best_ge, prm);
+        if (better) {
+#if SDM_K1_OPT & 0x4000
+            asm volatile("" ::: "memory");  // not if-convertible: the four moves run under the exec mask
+#endif
+            S.best_pixel = uj;
+            S.old_err = e;
+            S.best_pe = pe;
+            S.best_ge = ge;
+        }
+        return;
+    }
+#endif
+#if SDM_K1_OPT & 0x08
+    float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
+#else
+    float err = match_cost(pe * pe, ge * ge, prm);
+#endif
+    if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
+        S.best_pixel = uj;
+        S.old_err = err;
+        S.best_pe = pe;
+        S.best_ge = ge;
+    }
+}
+
 template <bool STATS, bool CLEAN, int NB>
 __device__ __forceinline__ void scan_batch(const ScanConst& q, int u0, float u0f, const DevParams& prm, ScanState& S,
                                            SearchStats* st)
@@ -664,64 +729,9 @@ __device__ __forceinline__ void scan_batch(const ScanConst& q, int u0, float u0f
     for (int k = 0; k < NB; k++) {
         const int uj = u0 + k;
         if (STATS && uj <= q.hi) st->candidates++;
-        const float yf = yfs[k];
         const float4 r = make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w);
         if (!((uj <= q.hi) & __builtin_amdgcn_inverse_ballot_w64(rowok[k]))) continue;  // PM.cc:408 + N3 (NaN rows fail)
-        if (r.x < prm.lambdaG) continue;                            // PM.cc:411
-#if SDM_ABLATE == 4
-        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-        continue;
-#endif
-        const float d2 = r.y - q.th_line;     // PM.cc:415-416
-        const float d3 = r.y - q.ang_pi_rot;  // PM.cc:427
-#if SDM_K1_OPT & 0x04
-        bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
-#else
-        bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
-#endif
-        if (!CLEAN) {
-            if (__builtin_expect(!((d2 < q.gate_lim) & (d3 < q.gate_lim)), 0))
-                fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
-        }
-        if (fail) continue;  // PM.cc:421,431
-        if (STATS) st->gate_pass++;
-#if SDM_ABLATE == 3 || SDM_ABLATE == 4
-        if (r.z > S.old_err) { S.best_pixel = uj; S.old_err = r.z; }
-        continue;
-#endif
-        const float y0w = lerp_w0(yf);                     // yf is in [1, H-1) here
-        float pe = q.pixel - rec_lerp_im_w(r, y0w);        // PM.cc:433
-        float ge = q.grad1 - rec_lerp_grad_w(r, y0w);      // PM.cc:434
-#if SDM_K1_OPT & 0x2000
-        if (CLEAN) {  // (this instantiation also implies theta_var == 0.23)
-            // S.old_err holds the APPROXIMATE cost of the best candidate so far (1e6 exactly before the first)
-            const float e = match_cost_approx(pe * pe, ge * ge);
-            bool better = e < S.old_err;
-            if (__builtin_expect((__float_as_uint(e) - __float_as_uint(S.old_err) + COST_BAND) <= 2u * COST_BAND, 0))
-                better = match_cost_ref(pe * pe, ge * ge, prm) < match_cost_ref(S.best_pe * S.best_pe, S.best_ge * S.best_ge, prm);
-            if (better) {
-#if SDM_K1_OPT & 0x4000
-                asm volatile("" ::: "memory");  // not if-convertible: the four moves run under the exec mask
-#endif
-                S.best_pixel = uj;
-                S.old_err = e;
-                S.best_pe = pe;
-                S.best_ge = ge;
-            }
-            continue;
-        }
-#endif
-#if SDM_K1_OPT & 0x08
-        float err = match_cost1(pe * pe, ge * ge, prm);    // PM.cc:436
-#else
-        float err = match_cost(pe * pe, ge * ge, prm);
-#endif
-        if (err < S.old_err) {  // PM.cc:437 strict: lowest uj wins ties
-            S.best_pixel = uj;
-            S.old_err = err;
-            S.best_pe = pe;
-            S.best_ge = ge;
-        }
+        scan_candidate<STATS, CLEAN>(q, uj, yfs[k], r, prm, S, st);
     }
 }
 
@@ -732,6 +742,130 @@ __device__ __forceinline__ void scan_segment(const ScanConst& q, int lo, const D
     float u0f = (float)lo;  // (float)uj without a conversion per candidate: exact below 2^24
     for (int u0 = lo; u0 <= q.hi; u0 += SCAN_UNROLL, u0f += (float)SCAN_UNROLL)
         scan_batch<STATS, CLEAN, SCAN_UNROLL>(q, u0, u0f, prm, S, st);
+}
+
+// ---- the scan over a gradient-gate bit plane (long ranges) -------------------------------------------------------------------
+// Far from the true match most candidates of a long range fail the gradient gate (PM.cc:411: ~80 % of an image does), and the
+// batched scan above still pays a 16-byte gather and the row / range tests for each of them.  Every keyframe slot therefore
+// carries a bit plane of that gate, gmask[y][x] = !(GradImg(y,x) < lambdaG), written with its records (sdm_ingest.h): one
+// 8-byte load answers the gate for up to 33 consecutive columns of one image row, and only the candidates whose bit is set are
+// visited -- in increasing uj, with the reference's statements (scan_candidate), so the arg-min is the reference's.
+// The candidates uj = u .. u+n of a lane lie in ONE row when n is small enough:  yf(uj) = -((a/b)*uj + c/b) as computed in float
+// is weakly monotone in uj (a product and a sum by constants, each rounded to nearest: rounding is monotone) and stays within
+// E of the real line through the float values a/b, c/b -- E < 2^-11 + 2^-9 for |a/b| <= 4, uj < 2^14, |yf| < 2^14 (one
+// rounding of the product, one of the sum).  So with f = yf(u) - floor(yf(u)), moving AWAY from the row boundary on the
+// monotone side costs nothing, and towards the other boundary every uj with |a/b| * (uj - u) < room - 2E, room = f (falling
+// line) or 1 - f (rising line), has floor(yf(uj)) = floor(yf(u)).  MASK_EPS = 2^-6 > 2E; the column count comes from an
+// approximate reciprocal shortened by 2^-9, i.e. is never too large.  A bit that is set for a candidate the gate would
+// reject (a plane built under a smaller lambdaG) is harmless: scan_candidate tests the record again.
+// Candidates whose row test fails (PM.cc:408 + N3) are stepped over one at a time -- unless the LAST candidate of the range
+// lies outside the image on the same side: by monotonicity so does everything in between, and the scan ends.
+#ifndef SDM_MASK_MIN_L
+#define SDM_MASK_MIN_L 12  // a wave takes the mask scan when at least half of its searching lanes have this many candidates ...
+#endif
+#ifndef SDM_MASK_MAX_SLOPE
+#define SDM_MASK_MAX_SLOPE 0.25f  // ... and no lane's line is steeper than this (a row run is ~1/slope columns)
+#endif
+#ifndef SDM_MASK_PREFETCH
+#define SDM_MASK_PREFETCH 1  // the next listed candidate's record is requested before the current one is evaluated
+#endif
+constexpr float MASK_EPS = 0x1p-6f;
+struct MaskStats {
+    unsigned long long waves, steps, row_mismatch;
+};
+template <bool STATS, bool CLEAN>
+__device__ __forceinline__ void scan_masked(const ScanConst& q, const char* __restrict__ mbase, unsigned mpitch, int lo,
+                                            const DevParams& prm, ScanState& S, SearchStats* st, MaskStats* ms)
+{
+    const float yh = -(q.ab * (float)q.hi + q.cb);  // the last candidate's row coordinate
+    const float inv_s = __builtin_amdgcn_rcpf(fabsf(q.ab)) * 0.998046875f;  // columns per unit of row room, shortened by 2^-9
+    const bool falling = q.ab > 0.0f;  // yf decreases with uj
+    // Two phases per chunk of 64 candidates, so that the lanes of a wave -- whose row runs start and end at different
+    // columns -- stay together: (1) the listed candidates of the chunk as ONE lane-private bit set, cand bit k = candidate
+    // base + k passes the row test and its gradient bit is set; (2) one listed candidate per lane and iteration.
+    for (int base = lo; base <= q.hi; base += 64) {
+        const int chi = min(q.hi, base + 63);
+        unsigned long long cand = 0ull;
+        bool ended = false;
+        int u = base;
+        while (u <= chi) {
+            const float yf = -(q.ab * (float)u + q.cb);  // PM.cc:407,433
+            const float yc = __builtin_amdgcn_fmed3f(yf, 1.0f, q.hlim_b);
+            if (!(yc == yf)) {  // PM.cc:408 + N3: this candidate's row is outside [1, H-2] (or NaN)
+                const bool out_lo = (yf < 1.0f) & (yh < 1.0f), out_hi = (yf > q.hlim_b) & (yh > q.hlim_b);
+                if (!(yf == yf) | out_lo | out_hi) {  // ... and so is every later one: the range ends here
+                    if (STATS) st->candidates += (unsigned long long)(q.hi - u + 1);
+                    ended = true;
+                    break;
+                }
+                if (STATS) st->candidates++;
+                u++;
+                continue;
+            }
+            const float fr = __builtin_amdgcn_fractf(yf);
+            const float room = (falling ? fr : 1.0f - fr) - MASK_EPS;
+            const int n = max(cvt_i32_sat(room * inv_s), 0);  // (0 * Inf = NaN -> 0; a negative room -> 0)
+            const int cover = min(min(n, chi - u), 32);       // columns u .. u+cover share the row; the load's window holds >= 33
+            const unsigned row = (unsigned)(int)yc;
+            const unsigned moff = __umul24(row, mpitch) + (((unsigned)u >> 5) << 2);
+            typedef unsigned mword2 __attribute__((ext_vector_type(2), aligned(4)));
+            const mword2 mw = *reinterpret_cast<const mword2*>(mbase + moff);
+            unsigned long long bits = (((unsigned long long)mw.y << 32) | (unsigned long long)mw.x) >> ((unsigned)u & 31u);
+            bits &= (2ull << cover) - 1ull;
+            cand |= bits << (unsigned)(u - base);
+            if (STATS) {
+                st->candidates += (unsigned long long)(cover + 1);
+                ms->steps++;
+            }
+            u += cover + 1;
+        }
+        if (STATS) {  // self-check of the row runs: the bit set against one lookup per candidate at the candidate's own row
+            for (int k = 0; base + k <= (ended ? u - 1 : chi); k++) {
+                const float yk = -(q.ab * (float)(base + k) + q.cb);
+                bool want = false;
+                if (__builtin_amdgcn_fmed3f(yk, 1.0f, q.hlim_b) == yk) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(mbase + (__umul24((unsigned)(int)yk, mpitch) +
+                                                                                   (((unsigned)(base + k) >> 5) << 2)));
+                    want = (w >> ((unsigned)(base + k) & 31u)) & 1u;
+                }
+                if (want != (bool)((cand >> k) & 1ull)) ms->row_mismatch++;
+            }
+        }
+        // phase 2: the listed candidates in increasing uj; each one's row comes from its own yf (it passed the row test)
+        const int cbase = base;
+#if SDM_MASK_PREFETCH
+        if (cand != 0ull) {
+            int uj = cbase + (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            float yfn = -(q.ab * (float)uj + q.cb);
+            v4f rn = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfn, q.W16) + ((unsigned)uj << 4)));
+            for (;;) {
+                const v4f rc = rn;
+                const int ujc = uj;
+                const float yfj = yfn;
+                const bool more = cand != 0ull;
+                if (more) {
+                    uj = cbase + (int)__builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    yfn = -(q.ab * (float)uj + q.cb);
+                    rn = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfn, q.W16) + ((unsigned)uj << 4)));
+                }
+                scan_candidate<STATS, CLEAN>(q, ujc, yfj, make_float4(rc.x, rc.y, rc.z, rc.w), prm, S, st);
+                if (!more) break;
+            }
+        }
+#else
+        while (cand != 0ull) {
+            const int uj = cbase + (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const float yfj = -(q.ab * (float)uj + q.cb);
+            v4f rc = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfj, q.W16) + ((unsigned)uj << 4)));
+            asm volatile("" : "+v"(rc));
+            scan_candidate<STATS, CLEAN>(q, uj, yfj, make_float4(rc.x, rc.y, rc.z, rc.w), prm, S, st);
+        }
+#endif
+        if (ended) break;
+    }
 }
 
 // Wave-uniform plan (K1: all 64 lanes of the wave are here together): the wave's LONGEST range, Lmax candidates, is covered
@@ -773,13 +907,16 @@ __device__ __forceinline__ void scan_planned(const ScanConst& q, int lo, int Lma
 // clean: PairConst::clean (wave-uniform).
 // PLAN: the wave-uniform scan plan (scan_planned) -- every lane of the wave must make this call together, lanes without a
 // pixel with on = false.  Without it (per-pixel entry points) `on` must be true.
+// mbase / mpitch: the neighbour keyframe's gradient-gate bit plane and its row pitch in bytes (scan_masked), or null: the
+// lanes of the wave that reach the scan together then choose between the two scans (DevParams::scan_mode).
 template <bool STATS, bool PLAN = false>
 __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
                                                 const float* __restrict__ cv, const float* __restrict__ rcv, int clean,
                                                 bool on, int x, int y, float pixel, float grad1,
                                                 float th_pi, float xp0, float xp1, const DevParams& prm, float& rho_o,
                                                 float& sigma_o, float& best_u, float& best_v,
-                                                SearchStats* st)
+                                                SearchStats* st, const char* __restrict__ mbase = nullptr, unsigned mpitch = 0,
+                                                MaskStats* ms = nullptr)
 {
     float fx = rcv[0], cx = rcv[1];
     const float mind = rcv[2], maxd = rcv[3];
@@ -874,12 +1011,32 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         }
         if (!live) return false;
     } else {
+        // which scan: a wave-uniform choice over the lanes that got here (the others returned above).  The mask scan pays
+        // when ranges are long -- most of their candidates fail the gradient gate -- and lines are flat enough for a row run
+        // to span many columns
+        bool masked = false;
+        const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+        if (mbase != nullptr && prm.scan_mode != 1) {
+            const unsigned long long lng = __builtin_amdgcn_ballot_w64(hi - lo + 1 >= SDM_MASK_MIN_L);
+            const unsigned long long steep = __builtin_amdgcn_ballot_w64(fabsf(ab) > SDM_MASK_MAX_SLOPE);
+            masked = prm.scan_mode == 2 || (2 * __popcll(lng) >= __popcll(here) && steep == 0ull);
+        }
+        if (masked) {
+            if (STATS && (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__builtin_ctzll(here)) ms->waves++;
 #if SDM_K1_OPT & 0x02
-        if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
-            scan_segment<STATS, true>(sc, lo, prm, S, st);
-        else
+            if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
+                scan_masked<STATS, true>(sc, mbase, mpitch, lo, prm, S, st, ms);
+            else
 #endif
-            scan_segment<STATS, false>(sc, lo, prm, S, st);
+                scan_masked<STATS, false>(sc, mbase, mpitch, lo, prm, S, st, ms);
+        } else {
+#if SDM_K1_OPT & 0x02
+            if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
+                scan_segment<STATS, true>(sc, lo, prm, S, st);
+            else
+#endif
+                scan_segment<STATS, false>(sc, lo, prm, S, st);
+        }
     }
     const float best_pe = S.best_pe, best_ge = S.best_ge;
     const int best_pixel = S.best_pixel;

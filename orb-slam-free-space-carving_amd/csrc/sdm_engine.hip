@@ -117,6 +117,12 @@ struct sdm_ctx {
     int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
     int nseg = 0;                              // H * tiles_x
     unsigned long long* d_act_hash = nullptr;  // [max_keyframes] hash of the active-pixel set (compact wire header)
+    unsigned long long* d_gmask = nullptr;     // [max_keyframes][H][mrow] gradient-gate bit plane of every slot: bit x%64 of word
+                                               // x/64 of row y = !(GradImg(y,x) < lambdaG), written with the slot's list
+                                               // (k_prepass_batch / k_gate_batch), read by K1's mask scan (sdm_device.h)
+    int mrow = 0;                              // 64-bit words per row: tiles_x + 1 (the last one stays zero: an 8-byte load at
+                                               // any 32-bit word of a row stays inside the row)
+    int scan_mode = 0;                         // DevParams::scan_mode (SDM_SCAN_MODE, read once in sdm_create)
     float* d_grad = nullptr;
     float* d_theta = nullptr;
     float* d_small = nullptr;  // 16 floats of per-pixel results
@@ -208,6 +214,7 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.inv_theta = 1 / c->prm.theta_var;  // (1/THETA), PM.cc:455
     c->dprm.fast_theta_div = (c->prm.theta_var == 0.23) ? 1 : 0;
     c->dprm.default_gates = (c->prm.lambdaL == 80.0f && c->prm.lambdaTheta == 45.0f) ? 1 : 0;
+    c->dprm.scan_mode = c->scan_mode;
 }
 
 int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
@@ -263,10 +270,11 @@ int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams
     if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, *q);
     if (from_images)
         hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P,
-                           c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg);
+                           c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask,
+                           c->mrow);
     else
         hipLaunchKernelGGL(k_gate_batch, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P, c->rec,
-                           c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg);
+                           c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask, c->mrow);
     hipLaunchKernelGGL(k_prepass_finish, dim3(m), dim3(FIN_BLOCK), 0, c->stream, B.d_items, c->W, c->H, ntiles, c->nseg, c->d_part,
                        c->d_seg_mask, c->d_seg_off, c->d_meta, c->d_act_count, c->d_theta_bad, c->d_act_hash,
                        from_images ? 1 : 0);
@@ -424,12 +432,18 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
     int rc;
-    {  // lists follow lambdaG (sdm_set_params)
+    {  // lists follow lambdaG (sdm_set_params); so do the gradient-gate bit planes K1's scan reads of the NEIGHBOURS
         std::vector<int> stale;
-        for (int r = 0; r < n_ref; r++)
-            if (!(c->act_lambdaG[ref_slots[r]] == c->dprm.lambdaG) &&
-                std::find(stale.begin(), stale.end(), ref_slots[r]) == stale.end())
-                stale.push_back(ref_slots[r]);
+        std::vector<char> seen((size_t)c->cfg.max_keyframes, 0);
+        auto look = [&](int slot) {
+            if (!(c->act_lambdaG[slot] == c->dprm.lambdaG) && !seen[slot]) {
+                seen[slot] = 1;
+                stale.push_back(slot);
+            }
+        };
+        for (int r = 0; r < n_ref; r++) look(ref_slots[r]);
+        if (need_consts)
+            for (size_t i = 0; i < (size_t)n_ref * (size_t)n; i++) look(nbr_slots[i]);
         if (!stale.empty() && (rc = rebuild_lists(c, (int)stale.size(), stale.data()))) return rc;
     }
     if ((rc = sync_counts(c))) return rc;  // callers size their grids from h_act_count
@@ -737,6 +751,10 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
             (rc = dev_alloc(&c->d_seg_mask, (size_t)c->ing_cap * c->nseg)) ||
             (rc = dev_alloc(&c->d_seg_off, (size_t)c->ing_cap * c->nseg)) || (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
             return bail(rc);
+        c->mrow = c->geom.tiles_x + 1;
+        if ((rc = dev_alloc(&c->d_gmask, (size_t)K * c->H * c->mrow))) return bail(rc);
+        if (const char* e = getenv("SDM_SCAN_MODE")) c->scan_mode = std::max(0, std::min(2, atoi(e)));  // tests / A-B
+        set_dev_params(c);
     }
     if ((rc = dev_alloc(&c->d_im, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
@@ -765,6 +783,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->d_act_count, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_theta_bad, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_act_hash, 0, sizeof(unsigned long long) * K, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_gmask, 0, sizeof(unsigned long long) * (size_t)K * c->H * c->mrow, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -821,6 +840,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_seg_mask);
     (void)hipFree(c->d_seg_off);
     (void)hipFree(c->d_act_hash);
+    (void)hipFree(c->d_gmask);
     (void)hipFree(c->d_im);
     (void)hipFree(c->d_grad);
     (void)hipFree(c->d_theta);
@@ -1247,11 +1267,11 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
         if (c->stats_on)
             hipLaunchKernelGGL(k_search_fuse<true>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
                                c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
-                               c->d_act, c->pool, c->d_stats, ol);
+                               c->d_act, c->pool, c->d_stats, ol, c->d_gmask, c->mrow);
         else
             hipLaunchKernelGGL(k_search_fuse<false>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
                                c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
-                               c->d_act, c->pool, c->d_stats, ol);
+                               c->d_act, c->pool, c->d_stats, ol, c->d_gmask, c->mrow);
     });
     if (c->stats_on)
         hipLaunchKernelGGL(k_fuse_open<true>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,
@@ -1766,7 +1786,7 @@ int sdm_epipolar_search(sdm_ctx* c, int ref_slot, int nbr_slot, int x, int y, fl
     int rc = stage_tables(c, 1, &ref_slot, 1, &nbr_slot, &rot, &mind, &maxd, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_epipolar_search_px, dim3(1), dim3(1), 0, c->stream, c->rec, c->P, c->d_refs, c->d_pairs, c->W,
-                       c->H, x, y, c->dprm, c->d_small);
+                       c->H, x, y, c->dprm, c->d_small, c->d_gmask, c->mrow);
     HIP_TRY(hipGetLastError());
     if ((rc = tables_staged(c))) return rc;
     return read_small(c, out, 5);
@@ -1951,6 +1971,15 @@ int sdm_get_timing(sdm_ctx* c, double ms_total[SDM_NUM_STAGES], long long launch
     return SDM_OK;
 }
 
+int sdm_set_scan_mode(sdm_ctx* c, int mode)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    if (mode < 0 || mode > 2) return fail(SDM_EINVAL, "scan mode must be 0, 1 or 2");
+    c->scan_mode = mode;
+    set_dev_params(c);
+    return SDM_OK;
+}
+
 int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
 {
     if (!c || !out) return fail(SDM_EINVAL, "null argument");
@@ -1962,6 +1991,9 @@ int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
     out->gate_pass = (long long)v[2];
     out->hypotheses = (long long)v[3];
     out->fused = (long long)v[4];
+    out->mask_waves = (long long)v[5];
+    out->mask_steps = (long long)v[6];
+    out->mask_row_mismatch = (long long)v[7];
     if (reset) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(v), c->stream));
     return SDM_OK;
 }

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
                                                          float2* __restrict__ pool, float* __restrict__ chk,
                                                          float* __restrict__ xyz, float lambdaG,
                                                          unsigned long long* __restrict__ part,
-                                                         unsigned long long* __restrict__ seg_mask, int nseg)
+                                                         unsigned long long* __restrict__ seg_mask, int nseg,
+                                                         unsigned long long* __restrict__ gmask, int mrow)
 {
     __shared__ uint8_t t[PRE_HALO_H][PRE_HALO_W];
     __shared__ float gm[TILE_H + 1][TILE_W];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
         const int ly = i * (BLOCK / 64) + wv;
         const int x = tx0 + lx, y = ty0 + ly;
         const bool in = x < W && y < H;
-        bool gate = false;
+        bool gate = false, sgate = false;
         if (in) {
             const bool below = y + 1 < H;
             const unsigned bits = (unsigned)t[ly + 1][lx + 1] | ((below ? (unsigned)t[ly + 2][lx + 1] : 0u) << 8);
@@ -226,11 +227,16 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
                 }
             }
             gate = act_gate(r.x, x, y, W, H, lambdaG);
+            sgate = !(r.x < lambdaG);  // the scan's gate on this pixel as a CANDIDATE of another keyframe's search, PM.cc:411
             if (gate) acc[2] += list_hash_term(((unsigned)y << 16) | (unsigned)x);
             if (!(r.y >= 0.0f && r.y <= 360.0f)) acc[3] = 1ull;  // never from fastAtan2; kept for symmetry with k_pack
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sgate);
+        if (lx == 0 && y < H) {
+            seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+            gmask[((long long)slot * H + y) * mrow + tx] = sm;  // the slot's gradient-gate bit plane (sdm_device.h scan_masked)
+        }
     }
     block_sum4(acc, red);
     if (tid < PART_WORDS) {
@@ -245,7 +251,8 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
 __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restrict__ items, int W, int H, int tiles_x,
                                                       long long plane, const float4* __restrict__ rec, float lambdaG,
                                                       unsigned long long* __restrict__ part,
-                                                      unsigned long long* __restrict__ seg_mask, int nseg)
+                                                      unsigned long long* __restrict__ seg_mask, int nseg,
+                                                      unsigned long long* __restrict__ gmask, int mrow)
 {
     __shared__ unsigned long long red[PART_WORDS * (BLOCK / 64)];
     const int kf = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
@@ -257,11 +264,19 @@ __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restri
 #pragma unroll
     for (int i = 0; i < PX_PER_THREAD; i++) {
         const int x = tx * TILE_W + lx, y = ty * TILE_H + i * (BLOCK / 64) + wv;
-        bool gate = false;
-        if (x < W && y < H) gate = act_gate(r[(long long)y * W + x].x, x, y, W, H, lambdaG);
+        bool gate = false, sgate = false;
+        if (x < W && y < H) {
+            const float g = r[(long long)y * W + x].x;
+            gate = act_gate(g, x, y, W, H, lambdaG);
+            sgate = !(g < lambdaG);
+        }
         if (gate) acc[2] += list_hash_term(((unsigned)y << 16) | (unsigned)x);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sgate);
+        if (lx == 0 && y < H) {
+            seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+            gmask[((long long)slot * H + y) * mrow + tx] = sm;
+        }
     }
     block_sum4(acc, red);
     if (tid < PART_WORDS) {

@@ -372,7 +372,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
                                                        int W, int H, int max_chunks, DevParams prm,
                                                        const unsigned* __restrict__ act, float2* __restrict__ pool,
-                                                       unsigned long long* __restrict__ stats, OpenList open_list)
+                                                       unsigned long long* __restrict__ stats, OpenList open_list,
+                                                       const unsigned long long* __restrict__ gmask, int mrow)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // [n][64] {rho, 1/sigma^2 (NaN = take the exact path)}: all a pair test reads; sigma itself is needed only by
@@ -419,6 +420,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         xp1 = ((float)y - rc.cy) / rc.fy;
     }
     SearchStats st = {0, 0, 0};
+    MaskStats ms = {0, 0, 0};
+    const unsigned mpitch = (unsigned)mrow << 3;  // bytes per row of a gradient-gate bit plane
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
     const float* __restrict__ rcv = rcvb;
@@ -446,8 +449,9 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         if (on) {
             float rho, sigma, bu, bv;
             const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
+            const char* __restrict__ mb = reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * mrow);
             bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, true, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
-                                             sigma, bu, bv, &st);
+                                             sigma, bu, bv, &st, gmask ? mb : nullptr, mpitch, &ms);
             if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
                 h = make_float2(rho, sigma);
                 mymask |= 1ull << j;
@@ -624,10 +628,10 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         pool[(long long)rc.slot * plane + y * W + x] = result;
     }
     if (STATS) {
-        unsigned long long v[5] = {st.searches, st.candidates, st.gate_pass,
-                                   (w == 0 && on) ? (unsigned long long)nh : 0ull, n_fused};
+        unsigned long long v[8] = {st.searches, st.candidates, st.gate_pass,
+                                   (w == 0 && on) ? (unsigned long long)nh : 0ull, n_fused, ms.waves, ms.steps, ms.row_mismatch};
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 8; k++) {
             unsigned long long s = v[k];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
             if ((tid & 63) == 0 && s) atomicAdd(&stats[k], s);
@@ -1654,7 +1658,7 @@ __global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict
 // ---- single-thread kernels behind the per-pixel C entry points ------------------------------------------------
 __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long plane, const RefConst* refs,
                                      const PairConst* pairs, int W, int H, int x, int y, DevParams prm,
-                                     float* __restrict__ out)
+                                     float* __restrict__ out, const unsigned long long* __restrict__ gmask, int mrow)
 {
     const RefConst rc = refs[0];
     const PairConst* pc = pairs;
@@ -1667,7 +1671,10 @@ __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long p
     SearchStats st = {0, 0, 0};
     const float* cv = reinterpret_cast<const float*>(pc);
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
-    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, true, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st);
+    MaskStats ms = {0, 0, 0};
+    const char* mb = reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * mrow);
+    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, true, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st,
+                                     gmask ? mb : nullptr, (unsigned)mrow << 3, &ms);
     out[0] = rho;
     out[1] = sigma;
     out[2] = ok ? 1.f : 0.f;

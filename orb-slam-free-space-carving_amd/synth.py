@@ -157,11 +157,12 @@ class Scene:
             d += 1
         return out
 
-    def depth_prior(self):
+    def depth_prior(self, spread=0.1):
         """(min_depth, max_depth) exactly as StereoSearchConstraints names them (PM.cc:381-382):
-        inverse depths 1/(mu-2s), 1/(mu+2s) with mu = Z0, s = 0.1*Z0, computed in float32."""
+        inverse depths 1/(mu-2s), 1/(mu+2s) with mu = Z0, s = spread*Z0 (App. D: 0.1; the ORB depths of a real keyframe
+        spread more like 0.3 ... 0.5 of their mean, and the reference does not guard mu - 2s <= 0), computed in float32."""
         mu = np.float32(self.z0)
-        sd = np.float32(0.1) * mu
+        sd = np.float32(spread) * mu
         max_depth = np.float32(1) / (mu + np.float32(2) * sd)
         min_depth = np.float32(1) / (mu - np.float32(2) * sd)
         return float(min_depth), float(max_depth)

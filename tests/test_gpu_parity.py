@@ -160,7 +160,8 @@ def test_search_fuse_stats(pkg, oracle, gpu_ok, seq_mid):
     got = eng.get_stats()
     _, _, ref = oracle.recon_search_fuse(seq_mid.okf[3], [seq_mid.okf[j] for j in nb], None, seq_mid.min_depth,
                                          seq_mid.max_depth)
-    assert got == ref
+    assert {k: got[k] for k in ref} == ref  # (the mask_* fields say how the ranges were walked, not what was found)
+    assert got["mask_row_mismatch"] == 0
     eng.close()
 
 

@@ -17,6 +17,8 @@ ap.add_argument("--nbrs", type=int, default=20)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--disparity", type=float, default=2.6)
+ap.add_argument("--spread", type=float, default=0.1, help="depth prior s = spread * mu (PM.cc:381-382)")
+ap.add_argument("--scan-mode", type=int, default=-1, help="sdm_set_scan_mode: 0 per wave, 1 batched, 2 gradient mask")
 ap.add_argument("--check", action="store_true", help="compare K1 maps with the default library's (bit-exact)")
 ap.add_argument("--outliers", type=int, default=0,
                 help="replace this many of every keyframe's neighbours by a copy with a wrong pose (baseline stretched by "
@@ -24,8 +26,10 @@ ap.add_argument("--outliers", type=int, default=0,
 ap.add_argument("--noise", action="store_true", help="i.i.d. uniform u8 images (nothing fuses cleanly: every pixel is open)")
 a = ap.parse_args()
 pkg = sdm_pkg.load()
-wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0, noise=a.noise)
+wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0, noise=a.noise, spread=a.spread)
 eng, pl = wl.eng, wl.pl
+if a.scan_mode >= 0:
+    eng.set_scan_mode(a.scan_mode)
 if a.outliers:
     # a second engine with kfs extra slots holding wrong-pose copies; neighbour j of keyframe k at list position
     # 3, 7, 11, ... is redirected to the copy of j
@@ -60,8 +64,9 @@ for _ in range(a.rounds):  # per-round means: the minimum / median over rounds i
 rounds.sort()
 ms = rounds[len(rounds) // 2]
 alg = wl.P * (17 + 9 * a.nbrs) * a.kfs
-print("%s K1 median %.4f ms (min %.4f, max %.4f over %d rounds x %d)  frac %.4f" % (
-    os.environ.get("SDM_LIB_PATH", "default"), ms, rounds[0], rounds[-1], a.rounds, a.reps, alg / (ms * 1e-3) / 1e9 / 8000.0))
+print("%s disp %.1f spread %.2f mode %d: K1 median %.4f ms (min %.4f, max %.4f over %d rounds x %d)  frac %.4f" % (
+    os.path.basename(os.environ.get("SDM_LIB_PATH", "default")), a.disparity, a.spread, a.scan_mode, ms, rounds[0], rounds[-1],
+    a.rounds, a.reps, alg / (ms * 1e-3) / 1e9 / 8000.0))
 if a.check:
     import hashlib
     h = hashlib.sha256()
