@@ -43,6 +43,8 @@ struct alignas(16) PairConst {  // per (reference, neighbour): hoisted out of th
                                 // (checked when the records are packed) and rot in [-360,360] -- the closed-form gates
                                 // then hold for every candidate and the scan drops their per-candidate precondition;
                                 // bit 1: line_quot_safe(F) -- the line's quotients need no per-lane guard
+                                // bit 2: the search range at the principal point spans at least MASK_HINT_L columns (or cannot be
+                                // told): K1's waves then ask themselves whether the mask scan pays (scan_masked)
     // -- the rest (K4, set-up) --
     float Ry[3];                // R21 row 1
     float ty;
@@ -744,45 +746,96 @@ __device__ __forceinline__ void scan_segment(const ScanConst& q, int lo, const D
         scan_batch<STATS, CLEAN, SCAN_UNROLL>(q, u0, u0f, prm, S, st);
 }
 
-// ---- the scan over a gradient-gate bit plane (long ranges) -------------------------------------------------------------------
-// Far from the true match most candidates of a long range fail the gradient gate (PM.cc:411: ~80 % of an image does), and the
-// batched scan above still pays a 16-byte gather and the row / range tests for each of them.  Every keyframe slot therefore
-// carries a bit plane of that gate, gmask[y][x] = !(GradImg(y,x) < lambdaG), written with its records (sdm_ingest.h): one
-// 8-byte load answers the gate for up to 33 consecutive columns of one image row, and only the candidates whose bit is set are
-// visited -- in increasing uj, with the reference's statements (scan_candidate), so the arg-min is the reference's.
-// The candidates uj = u .. u+n of a lane lie in ONE row when n is small enough:  yf(uj) = -((a/b)*uj + c/b) as computed in float
-// is weakly monotone in uj (a product and a sum by constants, each rounded to nearest: rounding is monotone) and stays within
-// E of the real line through the float values a/b, c/b -- E < 2^-11 + 2^-9 for |a/b| <= 4, uj < 2^14, |yf| < 2^14 (one
-// rounding of the product, one of the sum).  So with f = yf(u) - floor(yf(u)), moving AWAY from the row boundary on the
-// monotone side costs nothing, and towards the other boundary every uj with |a/b| * (uj - u) < room - 2E, room = f (falling
-// line) or 1 - f (rising line), has floor(yf(uj)) = floor(yf(u)).  MASK_EPS = 2^-6 > 2E; the column count comes from an
-// approximate reciprocal shortened by 2^-9, i.e. is never too large.  A bit that is set for a candidate the gate would
-// reject (a plane built under a smaller lambdaG) is harmless: scan_candidate tests the record again.
+// ---- the scan over gradient-gate bit planes (long ranges) -------------------------------------------------------------------
+// Far from the true match most candidates of a long range fail the gradient gate (PM.cc:411: ~80 % of an image does) or the
+// orientation gate against the reference pixel (PM.cc:427-431: a random edge passes with probability 1/4), and the batched
+// scan above still pays a 16-byte gather and the row / range tests for each of them.  Every keyframe slot therefore carries
+// bit planes of those gates, written with its records (sdm_ingest.h): MASK_PLANES dwords per (row, 32-column word), the planes
+// of one word side by side --
+//   plane b < 16:  bit x = !(GradImg(y,x) < lambdaG)  and  (GradTheta(y,x) in [22.5 b, 22.5 (b+1))  or  GradTheta(y,x) outside [0,360))
+//   planes 16-20:  bins 0-4 once more (a window that wraps past 360 is still six consecutive planes)
+//   plane 21:      bit x = !(GradImg(y,x) < lambdaG)                                (the union; NaN angles are in every plane)
+// A lane ORs the planes of the bins its orientation window [ang - lambdaTheta, ang + lambdaTheta] can touch (ang = the
+// reference pixel's GradTheta + rot, wrapped, PM.cc:424-426) -- 8-byte loads that answer both gates for up to 33 consecutive
+// columns of one image row -- and only the candidates whose bit is set are visited, in increasing uj, with the reference's
+// statements (scan_candidate: the exact gates run again), so the arg-min is the reference's.  The listing only has to be a
+// SUPERSET of the candidates that pass the gates:
+//   * bins: a candidate passes gate 3 iff the angular distance of its GradTheta to ang is <= lambdaTheta (both in [0,360): the
+//     reference's wrap, PM.cc:428-431; its float roundings move d by < 1e-4).  bin(t) = min(floor(t * 16/360), 15) in float is
+//     weakly monotone in t, so the bins bin(lo) .. bin(hi) of a window [lo, hi] hold every angle inside it, whatever the
+//     rounding at bin edges; the window is widened by MASK_ANG_MARGIN on both sides: at most MASK_WINDOW = 6 bins for the
+//     default lambdaTheta = 45.  Pairs that are not "clean" (an angle outside [0,360], PairConst::clean) and other thresholds
+//     use the union plane; pixels whose angle is outside [0,360) (caller-supplied planes only) sit in every plane.
+//   * rows: the candidates uj = u .. u+n of a lane lie in ONE row when n is small enough:  yf(uj) = -((a/b)*uj + c/b) as computed
+//     in float is weakly monotone in uj (a product and a sum by constants, each rounded to nearest: rounding is monotone) and
+//     stays within E of the real line through the float values a/b, c/b -- E < 2^-11 + 2^-9 for |a/b| <= 4, uj < 2^14,
+//     |yf| < 2^14 (one rounding of the product, one of the sum).  So with f = yf(u) - floor(yf(u)), moving AWAY from the row
+//     boundary on the monotone side costs nothing, and towards the other boundary every uj with |a/b| * (uj - u) < room - 2E,
+//     room = f (falling line) or 1 - f (rising line), has floor(yf(uj)) = floor(yf(u)).  MASK_EPS = 2^-6 > 2E; the column count
+//     comes from an approximate reciprocal shortened by 2^-9, i.e. is never too large.
+//   * a plane built under a smaller lambdaG only lists more.
 // Candidates whose row test fails (PM.cc:408 + N3) are stepped over one at a time -- unless the LAST candidate of the range
 // lies outside the image on the same side: by monotonicity so does everything in between, and the scan ends.
 #ifndef SDM_MASK_MIN_L
-#define SDM_MASK_MIN_L 12  // a wave takes the mask scan when at least half of its searching lanes have this many candidates ...
+#define SDM_MASK_MIN_L 24  // a wave takes the mask scan when at least half of its searching lanes have this many candidates ...
+#endif
+#ifndef SDM_MASK_MIN_L_UNION
+#define SDM_MASK_MIN_L_UNION 48  // (without the orientation window: pairs that are not clean, non-default thresholds)
 #endif
 #ifndef SDM_MASK_MAX_SLOPE
 #define SDM_MASK_MAX_SLOPE 0.25f  // ... and no lane's line is steeper than this (a row run is ~1/slope columns)
 #endif
-#ifndef SDM_MASK_PREFETCH
-#define SDM_MASK_PREFETCH 1  // the next listed candidate's record is requested before the current one is evaluated
+#ifndef SDM_MASK_NB
+#define SDM_MASK_NB 2  // listed candidates evaluated per iteration of phase 2 (their gathers are in flight together)
 #endif
+#ifndef SDM_MASK_BINS
+#define SDM_MASK_BINS 1  // 0: the union plane only (gradient gate)
+#endif
+constexpr int MASK_BINS = 16;
+constexpr int MASK_WINDOW = 6;                               // bins a window of 2 * (45 + margin) degrees can touch
+constexpr int MASK_UNION = MASK_BINS + MASK_WINDOW - 1;      // planes 16 .. 20 repeat bins 0 .. 4: a window is 6 CONSECUTIVE planes
+constexpr int MASK_PLANES = MASK_UNION + 1;                  // 22 dwords per (row, 32-column word): 88 bytes
+constexpr unsigned MASK_WORD_BYTES = 4u * MASK_PLANES;
 constexpr float MASK_EPS = 0x1p-6f;
+constexpr int MASK_HINT_L = SDM_MASK_MIN_L * 3 / 4;  // PairConst::clean bit 2
+#ifndef SDM_MASK_CALL_MEAN_L
+#define SDM_MASK_CALL_MEAN_L 32  // K1's mask-scan instantiation runs for calls whose mean range (principal point, all pairs) is at least this
+#endif
+constexpr int MASK_CALL_MEAN_L = SDM_MASK_CALL_MEAN_L;
+constexpr float MASK_ANG_MARGIN = 0.01f;
+constexpr float MASK_BIN_SCALE = (float)MASK_BINS / 360.0f;
+// the bin of an angle in [0,360): weakly monotone in t (product by a constant, floor, min)
+__host__ __device__ __forceinline__ int mask_bin(float t)
+{
+    const int b = (int)(t * MASK_BIN_SCALE);
+    return b < MASK_BINS - 1 ? b : MASK_BINS - 1;
+}
 struct MaskStats {
     unsigned long long waves, steps, row_mismatch;
 };
-template <bool STATS, bool CLEAN>
-__device__ __forceinline__ void scan_masked(const ScanConst& q, const char* __restrict__ mbase, unsigned mpitch, int lo,
-                                            const DevParams& prm, ScanState& S, SearchStats* st, MaskStats* ms)
+struct MaskView {  // one keyframe slot's planes
+    const char* base;    // row 0, word 0, plane 0
+    unsigned row_pitch;  // bytes per image row: 32-bit words per row x MASK_WORD_BYTES
+};
+// BINNED: the lane's orientation window (six planes); otherwise the union plane
+template <bool STATS, bool CLEAN, bool BINNED>
+__device__ __forceinline__ void scan_masked(const ScanConst& q, const MaskView& mv, int lo, const DevParams& prm, ScanState& S,
+                                            SearchStats* st, MaskStats* ms)
 {
     const float yh = -(q.ab * (float)q.hi + q.cb);  // the last candidate's row coordinate
     const float inv_s = __builtin_amdgcn_rcpf(fabsf(q.ab)) * 0.998046875f;  // columns per unit of row room, shortened by 2^-9
     const bool falling = q.ab > 0.0f;  // yf decreases with uj
+    // the first plane of the lane's window as a byte offset inside a word's planes (BINNED: ang is in [0,360))
+    unsigned pl0 = 4u * (unsigned)MASK_UNION;
+    if (BINNED) {
+        float w0 = q.ang_pi_rot - (45.0f + MASK_ANG_MARGIN);
+        if (w0 < 0.0f) w0 += 360.0f;
+        pl0 = 4u * (unsigned)mask_bin(w0);
+    }
     // Two phases per chunk of 64 candidates, so that the lanes of a wave -- whose row runs start and end at different
     // columns -- stay together: (1) the listed candidates of the chunk as ONE lane-private bit set, cand bit k = candidate
-    // base + k passes the row test and its gradient bit is set; (2) one listed candidate per lane and iteration.
+    // base + k passes the row test and its bit is set in one of the lane's planes; (2) SDM_MASK_NB listed candidates per lane
+    // and iteration.
     for (int base = lo; base <= q.hi; base += 64) {
         const int chi = min(q.hi, base + 63);
         unsigned long long cand = 0ull;
@@ -805,12 +858,23 @@ __device__ __forceinline__ void scan_masked(const ScanConst& q, const char* __re
             const float fr = __builtin_amdgcn_fractf(yf);
             const float room = (falling ? fr : 1.0f - fr) - MASK_EPS;
             const int n = max(cvt_i32_sat(room * inv_s), 0);  // (0 * Inf = NaN -> 0; a negative room -> 0)
-            const int cover = min(min(n, chi - u), 32);       // columns u .. u+cover share the row; the load's window holds >= 33
-            const unsigned row = (unsigned)(int)yc;
-            const unsigned moff = __umul24(row, mpitch) + (((unsigned)u >> 5) << 2);
-            typedef unsigned mword2 __attribute__((ext_vector_type(2), aligned(4)));
-            const mword2 mw = *reinterpret_cast<const mword2*>(mbase + moff);
-            unsigned long long bits = (((unsigned long long)mw.y << 32) | (unsigned long long)mw.x) >> ((unsigned)u & 31u);
+            const int cover = min(min(n, chi - u), 32);       // columns u .. u+cover share the row; the two words hold >= 33
+            const char* __restrict__ mp = mv.base + (__umul24((unsigned)(int)yc, mv.row_pitch) + __umul24((unsigned)u >> 5, MASK_WORD_BYTES) + pl0);
+            unsigned mlo, mhi;
+            if (BINNED) {  // six planes of this word and of the next one: 24 contiguous bytes each
+                typedef unsigned mword4 __attribute__((ext_vector_type(4), aligned(4)));
+                typedef unsigned mword2 __attribute__((ext_vector_type(2), aligned(4)));
+                const mword4 a0 = *reinterpret_cast<const mword4*>(mp);
+                const mword2 a1 = *reinterpret_cast<const mword2*>(mp + 16);
+                const mword4 b0 = *reinterpret_cast<const mword4*>(mp + MASK_WORD_BYTES);
+                const mword2 b1 = *reinterpret_cast<const mword2*>(mp + MASK_WORD_BYTES + 16);
+                mlo = (a0.x | a0.y | a0.z) | (a0.w | a1.x | a1.y);
+                mhi = (b0.x | b0.y | b0.z) | (b0.w | b1.x | b1.y);
+            } else {
+                mlo = *reinterpret_cast<const unsigned*>(mp);
+                mhi = *reinterpret_cast<const unsigned*>(mp + MASK_WORD_BYTES);
+            }
+            unsigned long long bits = (((unsigned long long)mhi << 32) | (unsigned long long)mlo) >> ((unsigned)u & 31u);
             bits &= (2ull << cover) - 1ull;
             cand |= bits << (unsigned)(u - base);
             if (STATS) {
@@ -819,51 +883,43 @@ __device__ __forceinline__ void scan_masked(const ScanConst& q, const char* __re
             }
             u += cover + 1;
         }
-        if (STATS) {  // self-check of the row runs: the bit set against one lookup per candidate at the candidate's own row
+        if (STATS) {  // self-check of the row runs and the bins: no candidate that passes the three gates may be missing
             for (int k = 0; base + k <= (ended ? u - 1 : chi); k++) {
                 const float yk = -(q.ab * (float)(base + k) + q.cb);
-                bool want = false;
-                if (__builtin_amdgcn_fmed3f(yk, 1.0f, q.hlim_b) == yk) {
-                    const unsigned w = *reinterpret_cast<const unsigned*>(mbase + (__umul24((unsigned)(int)yk, mpitch) +
-                                                                                   (((unsigned)(base + k) >> 5) << 2)));
-                    want = (w >> ((unsigned)(base + k) & 31u)) & 1u;
-                }
-                if (want != (bool)((cand >> k) & 1ull)) ms->row_mismatch++;
+                if (!(__builtin_amdgcn_fmed3f(yk, 1.0f, q.hlim_b) == yk)) continue;
+                const v4f r = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yk, q.W16) + ((unsigned)(base + k) << 4)));
+                if (r.x < prm.lambdaG) continue;
+                const bool fail = gate2_fails_ref(r.y - q.th_line, prm.lambdaL) || gate3_fails_ref(r.y - q.ang_pi_rot, prm.lambdaTheta);
+                if (!fail && !((cand >> k) & 1ull)) ms->row_mismatch++;
             }
         }
         // phase 2: the listed candidates in increasing uj; each one's row comes from its own yf (it passed the row test)
-        const int cbase = base;
-#if SDM_MASK_PREFETCH
-        if (cand != 0ull) {
-            int uj = cbase + (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            float yfn = -(q.ab * (float)uj + q.cb);
-            v4f rn = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfn, q.W16) + ((unsigned)uj << 4)));
-            for (;;) {
-                const v4f rc = rn;
-                const int ujc = uj;
-                const float yfj = yfn;
-                const bool more = cand != 0ull;
-                if (more) {
-                    uj = cbase + (int)__builtin_ctzll(cand);
-                    cand &= cand - 1ull;
-                    yfn = -(q.ab * (float)uj + q.cb);
-                    rn = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfn, q.W16) + ((unsigned)uj << 4)));
-                }
-                scan_candidate<STATS, CLEAN>(q, ujc, yfj, make_float4(rc.x, rc.y, rc.z, rc.w), prm, S, st);
-                if (!more) break;
+        while (cand != 0ull) {
+            int ujs[SDM_MASK_NB];
+            float yfs[SDM_MASK_NB];
+            v4f rs[SDM_MASK_NB];
+            unsigned long long okm[SDM_MASK_NB];
+#pragma unroll
+            for (int k = 0; k < SDM_MASK_NB; k++) {
+                okm[k] = __builtin_amdgcn_ballot_w64(cand != 0ull);  // (a lane mask in scalar registers, taken before the loads)
+                const int uj = base + (cand != 0ull ? (int)__builtin_ctzll(cand) : 0);
+                cand &= cand - 1ull;  // (0 stays 0)
+                const float yfj = -(q.ab * (float)uj + q.cb);
+                // a lane without a k-th candidate re-reads the chunk's first column at a clamped row: any valid address
+                const float ycj = __builtin_amdgcn_fmed3f(yfj, 1.0f, q.hlim_b);
+                ujs[k] = uj;
+                yfs[k] = yfj;
+                rs[k] = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)ycj, q.W16) + ((unsigned)uj << 4)));
+            }
+#pragma unroll
+            for (int k = 0; k < SDM_MASK_NB; k++)
+                asm volatile("" : "+v"(rs[k]));
+#pragma unroll
+            for (int k = 0; k < SDM_MASK_NB; k++) {
+                if (!__builtin_amdgcn_inverse_ballot_w64(okm[k])) continue;
+                scan_candidate<STATS, CLEAN>(q, ujs[k], yfs[k], make_float4(rs[k].x, rs[k].y, rs[k].z, rs[k].w), prm, S, st);
             }
         }
-#else
-        while (cand != 0ull) {
-            const int uj = cbase + (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            const float yfj = -(q.ab * (float)uj + q.cb);
-            v4f rc = *reinterpret_cast<const v4f*>(q.nbase + (__umul24((unsigned)(int)yfj, q.W16) + ((unsigned)uj << 4)));
-            asm volatile("" : "+v"(rc));
-            scan_candidate<STATS, CLEAN>(q, uj, yfj, make_float4(rc.x, rc.y, rc.z, rc.w), prm, S, st);
-        }
-#endif
         if (ended) break;
     }
 }
@@ -907,16 +963,17 @@ __device__ __forceinline__ void scan_planned(const ScanConst& q, int lo, int Lma
 // clean: PairConst::clean (wave-uniform).
 // PLAN: the wave-uniform scan plan (scan_planned) -- every lane of the wave must make this call together, lanes without a
 // pixel with on = false.  Without it (per-pixel entry points) `on` must be true.
-// mbase / mpitch: the neighbour keyframe's gradient-gate bit plane and its row pitch in bytes (scan_masked), or null: the
-// lanes of the wave that reach the scan together then choose between the two scans (DevParams::scan_mode).
-template <bool STATS, bool PLAN = false>
+// mv: the neighbour keyframe's gate bit planes (scan_masked), base == null: none; the lanes of the wave that reach the scan together choose
+// between the two scans (DevParams::scan_mode).
+// MASK: compile the mask scan in (K1 has an instantiation without it: on short ranges the mere presence of the second scan
+// costs the batched one 6 % -- register allocation around the pair's scalar constants).
+template <bool STATS, bool PLAN = false, bool MASK = false>
 __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec, int W, int H,
                                                 const float* __restrict__ cv, const float* __restrict__ rcv, int clean,
                                                 bool on, int x, int y, float pixel, float grad1,
                                                 float th_pi, float xp0, float xp1, const DevParams& prm, float& rho_o,
                                                 float& sigma_o, float& best_u, float& best_v,
-                                                SearchStats* st, const char* __restrict__ mbase = nullptr, unsigned mpitch = 0,
-                                                MaskStats* ms = nullptr)
+                                                SearchStats* st, const MaskView mv = MaskView{nullptr, 0u}, MaskStats* ms = nullptr)
 {
     float fx = rcv[0], cx = rcv[1];
     const float mind = rcv[2], maxd = rcv[3];
@@ -1016,19 +1073,27 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         // to span many columns
         bool masked = false;
         const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
-        if (mbase != nullptr && prm.scan_mode != 1) {
-            const unsigned long long lng = __builtin_amdgcn_ballot_w64(hi - lo + 1 >= SDM_MASK_MIN_L);
+#ifndef SDM_MASK_DISABLE  // (A/B builds: the batched scan alone, as rounds 1-4 shipped it)
+        // clean bit 2: the pair's range at the principal point is long enough for the question to be worth three ballots
+        if (MASK && mv.base != nullptr && prm.scan_mode != 1 && ((clean & 4) || prm.scan_mode == 2)) {
+            // the orientation window needs ang in [0,360) -- a clean pair -- and the default thresholds the planes are cut for;
+            // the gradient plane alone pays later
+            const bool binned = (clean & 1) && prm.default_gates && prm.fast_theta_div && SDM_MASK_BINS;
+            const int min_l = binned ? SDM_MASK_MIN_L : SDM_MASK_MIN_L_UNION;
+            const unsigned long long lng = __builtin_amdgcn_ballot_w64(hi - lo + 1 >= min_l);
             const unsigned long long steep = __builtin_amdgcn_ballot_w64(fabsf(ab) > SDM_MASK_MAX_SLOPE);
             masked = prm.scan_mode == 2 || (2 * __popcll(lng) >= __popcll(here) && steep == 0ull);
         }
-        if (masked) {
+#endif
+        if (MASK && masked) {
             if (STATS && (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__builtin_ctzll(here)) ms->waves++;
+            // the orientation window needs ang in [0,360) -- a clean pair -- and the default lambdaTheta the planes are cut for
 #if SDM_K1_OPT & 0x02
             if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
-                scan_masked<STATS, true>(sc, mbase, mpitch, lo, prm, S, st, ms);
+                scan_masked<STATS, true, SDM_MASK_BINS != 0>(sc, mv, lo, prm, S, st, ms);
             else
 #endif
-                scan_masked<STATS, false>(sc, mbase, mpitch, lo, prm, S, st, ms);
+                scan_masked<STATS, false, false>(sc, mv, lo, prm, S, st, ms);
         } else {
 #if SDM_K1_OPT & 0x02
             if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform

@@ -117,11 +117,12 @@ struct sdm_ctx {
     int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
     int nseg = 0;                              // H * tiles_x
     unsigned long long* d_act_hash = nullptr;  // [max_keyframes] hash of the active-pixel set (compact wire header)
-    unsigned long long* d_gmask = nullptr;     // [max_keyframes][H][mrow] gradient-gate bit plane of every slot: bit x%64 of word
-                                               // x/64 of row y = !(GradImg(y,x) < lambdaG), written with the slot's list
-                                               // (k_prepass_batch / k_gate_batch), read by K1's mask scan (sdm_device.h)
-    int mrow = 0;                              // 64-bit words per row: tiles_x + 1 (the last one stays zero: an 8-byte load at
-                                               // any 32-bit word of a row stays inside the row)
+    unsigned* d_gmask = nullptr;               // [max_keyframes][H][mrow][MASK_PLANES] gate bit planes of every slot, one dword
+                                               // per (row, 32-column word, plane): bit x%32 = pixel x passes the gradient gate (and
+                                               // its angle lies in the plane's bin), written with the slot's list (k_prepass_batch /
+                                               // k_gate_batch), read by K1's mask scan (sdm_device.h scan_masked)
+    int mrow = 0;                              // 32-bit words per image row: 2 * (tiles_x + 1) (the last two stay zero: the scan
+                                               // reads the word after the one a column lies in)
     int scan_mode = 0;                         // DevParams::scan_mode (SDM_SCAN_MODE, read once in sdm_create)
     float* d_grad = nullptr;
     float* d_theta = nullptr;
@@ -137,6 +138,7 @@ struct sdm_ctx {
     size_t tab_bytes = 0;
     struct TableKey {
         bool valid = false, has_consts = false;
+        bool long_ranges = false;  // some pair's search range at the principal point is long: K1 runs its mask-scan instantiation
         int n_ref = 0, n = 0;
         unsigned long long epoch = 0;
         std::vector<int> refs, nbrs;
@@ -514,14 +516,29 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     HIP_TRY(hipGetLastError());
     k.valid = true;
     k.has_consts = (n > 0) && mind && maxd;
-    k.n_ref = n_ref;
-    k.n = n;
-    k.epoch = c->epoch;
-    k.refs.assign(ref_slots, ref_slots + n_ref);
-    k.nbrs.assign(nbr_slots, nbr_slots + np);
-    k.rot.assign(h_rot, h_rot + np);
-    k.mind.assign(h_mind, h_mind + n_ref);
-    k.maxd.assign(h_maxd, h_maxd + n_ref);
+    k.long_ranges = false;
+    if (k.has_consts) {
+        // The search range of PM.cc:877-910 at the principal point (xp = (0, 0, 1)), averaged over the call's pairs, restated on
+        // the host: a hint that selects K1's instantiation (the device's own per-pair bit and the waves' range lengths decide
+        // each scan).  The mask-scan instantiation costs the batched scan 6 % (measured), so it only runs where the long
+        // ranges are the bulk of the work.
+        double sum = 0.0;
+        for (size_t i = 0; i < np; i++) {
+            const KfMeta& m1 = c->h_meta[ref_slots[i / (size_t)n]];
+            const KfMeta& m2 = c->h_meta[nbr_slots[i]];
+            float F[9], R21[9], t21[3];
+            pair_geometry(m1, m2, F, R21, t21);
+            const float d0 = h_mind[i / (size_t)n], d1 = h_maxd[i / (size_t)n];
+            float u0 = m1.fx * (R21[2] * d0 + t21[0]) / (R21[8] * d0 + t21[2]) + m1.cx;
+            float u1 = m1.fx * (R21[2] * d1 + t21[0]) / (R21[8] * d1 + t21[2]) + m1.cx;
+            const float cols = (float)c->W;
+            u0 = u0 < 0 ? 0 : (u0 > cols ? cols : u0);
+            u1 = u1 < 0 ? 0 : (u1 > cols ? cols : u1);
+            const float len = std::fabs(u1 - u0);
+            sum += (len == len) ? (double)len : (double)cols;  // (NaN ends: cannot tell -- count the pair as long)
+        }
+        k.long_ranges = np > 0 && sum / (double)np >= (double)MASK_CALL_MEAN_L;
+    }
     HIP_TRY(hipEventRecord(c->sets[victim].free_ev, c->stream));  // the pinned block may be rewritten after this point
     c->sets[victim].pending = true;
     c->sets[victim].last_use = ++c->use_tick;
@@ -751,8 +768,8 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
             (rc = dev_alloc(&c->d_seg_mask, (size_t)c->ing_cap * c->nseg)) ||
             (rc = dev_alloc(&c->d_seg_off, (size_t)c->ing_cap * c->nseg)) || (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
             return bail(rc);
-        c->mrow = c->geom.tiles_x + 1;
-        if ((rc = dev_alloc(&c->d_gmask, (size_t)K * c->H * c->mrow))) return bail(rc);
+        c->mrow = 2 * (c->geom.tiles_x + 1);
+        if ((rc = dev_alloc(&c->d_gmask, (size_t)K * c->H * MASK_PLANES * c->mrow))) return bail(rc);
         if (const char* e = getenv("SDM_SCAN_MODE")) c->scan_mode = std::max(0, std::min(2, atoi(e)));  // tests / A-B
         set_dev_params(c);
     }
@@ -783,7 +800,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->d_act_count, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_theta_bad, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_act_hash, 0, sizeof(unsigned long long) * K, c->stream) != hipSuccess ||
-        hipMemsetAsync(c->d_gmask, 0, sizeof(unsigned long long) * (size_t)K * c->H * c->mrow, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_gmask, 0, sizeof(unsigned) * (size_t)K * c->H * MASK_PLANES * c->mrow, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
@@ -791,10 +808,10 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
 
     // K1's hypothesis columns can need more than the default 64 KB of dynamic LDS
     const int max_lds = (int)k1_lds_bytes(cfg->max_neighbours);
-    if (hipFuncSetAttribute((const void*)k_search_fuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)k_search_fuse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) !=
-            hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_search_fuse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_search_fuse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_search_fuse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_search_fuse<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
         return bail(fail(SDM_EHIP, "hipFuncSetAttribute(max dynamic LDS) failed"));
     *out = c;
     return SDM_OK;
@@ -1263,15 +1280,14 @@ static int launch_search_fuse(sdm_ctx* c, int n_ref, int n, const int* ref_slots
     const size_t lds_open = (sizeof(float2) + sizeof(float)) * (size_t)K1_PX * n + sizeof(unsigned) * (size_t)K1_PX * ((n + 3) / 4);
     const int grid_open = (int)std::min<unsigned>(c->open_capacity / K1_PX, c->open_grid);
     // (the slices of one call append to the same open list; k_fuse_open runs once behind the last one)
+    // the mask-scan instantiation only where a pair of the call can use it (or the diagnostic mode asks for it)
+    const bool mask = c->scan_mode == 2 || (c->scan_mode == 0 && c->sets[c->cur_set].key.long_ranges);
+    auto k1 = c->stats_on ? (mask ? k_search_fuse<true, true> : k_search_fuse<true, false>)
+                          : (mask ? k_search_fuse<false, true> : k_search_fuse<false, false>);
     for_ref_slices(n_ref, blocks_per_ref, K1_BLOCK, [&](int first, int count) {
-        if (c->stats_on)
-            hipLaunchKernelGGL(k_search_fuse<true>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
-                               c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
-                               c->d_act, c->pool, c->d_stats, ol, c->d_gmask, c->mrow);
-        else
-            hipLaunchKernelGGL(k_search_fuse<false>, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P,
-                               c->d_refs + first, c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm,
-                               c->d_act, c->pool, c->d_stats, ol, c->d_gmask, c->mrow);
+        hipLaunchKernelGGL(k1, dim3(blocks_per_ref * count), dim3(K1_BLOCK), lds, c->stream, c->rec, c->P, c->d_refs + first,
+                           c->d_pairs + (size_t)first * n, count, n, c->W, c->H, max_chunks, c->dprm, c->d_act, c->pool, c->d_stats,
+                           ol, c->d_gmask, c->mrow);
     });
     if (c->stats_on)
         hipLaunchKernelGGL(k_fuse_open<true>, dim3(grid_open), dim3(K1_BLOCK), lds_open, c->stream, ol, n, c->dprm, c->pool,

@@ -150,6 +150,32 @@ __device__ __forceinline__ void scharr32(const uint8_t (*t)[PRE_HALO_W], int lx,
     centre = a11;
 }
 
+// One 64-pixel row segment's two words of the slot's gate bit planes (sdm_device.h scan_masked; every lane of the wave
+// calls): sgate = the scan's gradient gate on this pixel as a CANDIDATE of another keyframe's search (PM.cc:411), theta its
+// GradTheta.  Plane b < MASK_BINS holds the gated pixels whose angle falls into bin b -- and those whose angle is not in
+// [0,360) at all --, planes MASK_BINS .. MASK_UNION-1 repeat the first bins, plane MASK_UNION holds all gated pixels.  Lane p
+// stores plane p's two dwords (MASK_PLANES consecutive dwords per 32-column word).
+__device__ __forceinline__ void write_gate_planes(unsigned* __restrict__ gmask, long long row_dword0, int tx, bool sgate, float theta,
+                                                  bool store)
+{
+    const bool in_range = (theta >= 0.0f) & (theta < 360.0f);
+    const int bin = in_range ? mask_bin(theta) : -1;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int mybin = lane < MASK_BINS ? lane : lane - MASK_BINS;
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int b = 0; b < MASK_BINS; b++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sgate & ((bin == b) | !in_range));
+        if (mybin == b) mine = m;
+    }
+    const unsigned long long all = __builtin_amdgcn_ballot_w64(sgate);
+    if (lane == MASK_UNION) mine = all;
+    if (store && lane < MASK_PLANES) {
+        gmask[row_dword0 + (long long)(2 * tx) * MASK_PLANES + lane] = (unsigned)mine;
+        gmask[row_dword0 + (long long)(2 * tx + 1) * MASK_PLANES + lane] = (unsigned)(mine >> 32);
+    }
+}
+
 // grid (tiles, keyframes).  ZERO: the slot receives a new keyframe -- its depth map, checked plane and point set start
 // as zeros (a fresh KeyFrame's depth_map_ / depth_sigma_ / SemiDensePointSets_)
 template <bool ZERO>
@@ -159,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
                                                          float* __restrict__ xyz, float lambdaG,
                                                          unsigned long long* __restrict__ part,
                                                          unsigned long long* __restrict__ seg_mask, int nseg,
-                                                         unsigned long long* __restrict__ gmask, int mrow)
+                                                         unsigned* __restrict__ gmask, int mrow)
 {
     __shared__ uint8_t t[PRE_HALO_H][PRE_HALO_W];
     __shared__ float gm[TILE_H + 1][TILE_W];
@@ -232,11 +258,8 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
             if (!(r.y >= 0.0f && r.y <= 360.0f)) acc[3] = 1ull;  // never from fastAtan2; kept for symmetry with k_pack
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sgate);
-        if (lx == 0 && y < H) {
-            seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
-            gmask[((long long)slot * H + y) * mrow + tx] = sm;  // the slot's gradient-gate bit plane (sdm_device.h scan_masked)
-        }
+        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        write_gate_planes(gmask, ((long long)slot * H + y) * MASK_PLANES * mrow, tx, sgate, th[i], y < H);
     }
     block_sum4(acc, red);
     if (tid < PART_WORDS) {
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restri
                                                       long long plane, const float4* __restrict__ rec, float lambdaG,
                                                       unsigned long long* __restrict__ part,
                                                       unsigned long long* __restrict__ seg_mask, int nseg,
-                                                      unsigned long long* __restrict__ gmask, int mrow)
+                                                      unsigned* __restrict__ gmask, int mrow)
 {
     __shared__ unsigned long long red[PART_WORDS * (BLOCK / 64)];
     const int kf = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
@@ -265,18 +288,17 @@ __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restri
     for (int i = 0; i < PX_PER_THREAD; i++) {
         const int x = tx * TILE_W + lx, y = ty * TILE_H + i * (BLOCK / 64) + wv;
         bool gate = false, sgate = false;
+        float theta = 0.0f;
         if (x < W && y < H) {
-            const float g = r[(long long)y * W + x].x;
-            gate = act_gate(g, x, y, W, H, lambdaG);
-            sgate = !(g < lambdaG);
+            const float4 rr = r[(long long)y * W + x];
+            gate = act_gate(rr.x, x, y, W, H, lambdaG);
+            sgate = !(rr.x < lambdaG);
+            theta = rr.y;
         }
         if (gate) acc[2] += list_hash_term(((unsigned)y << 16) | (unsigned)x);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sgate);
-        if (lx == 0 && y < H) {
-            seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
-            gmask[((long long)slot * H + y) * mrow + tx] = sm;
-        }
+        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        write_gate_planes(gmask, ((long long)slot * H + y) * MASK_PLANES * mrow, tx, sgate, theta, y < H);
     }
     block_sum4(acc, red);
     if (tid < PART_WORDS) {

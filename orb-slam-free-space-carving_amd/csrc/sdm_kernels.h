@@ -202,6 +202,11 @@ __global__ void k_pair_setup(const KfMeta* __restrict__ meta, const int* __restr
     // in [-360,360]: the closed-form gates of the scan hold for every candidate of this pair (sdm_device.h)
     pc.clean = ((theta_bad[ref_slots[r]] == 0 && theta_bad[nbr_slots[idx]] == 0 && pc.rot >= -360.0f && pc.rot <= 360.0f) ? 1 : 0) |
                (line_quot_safe(pc.F) ? 2 : 0);
+    {  // bit 2: a long search range at the principal point (xp = (0, 0, 1): the ray dot products are the rows' last entries)
+        float umin, umax;
+        search_range(m1.fx, m1.cx, pc.Rx[2], pc.Rz[2], pc.tx, pc.tz, mind ? mind[r] : 0.f, maxd ? maxd[r] : 0.f, W, umin, umax);
+        if (!(umax - umin < (float)MASK_HINT_L)) pc.clean |= 4;  // (NaN ends: cannot tell)
+    }
     // K4's approximate projection (k4_proj_bounds): the largest |xp0|, |xp1| any pixel of the reference image can have
     {
         const float s = 1.0f + 0x1p-20f;
@@ -366,14 +371,16 @@ __device__ __forceinline__ bool k1_fuse_counted(const float2* hyp, const float* 
 #ifndef SDM_K1_LB
 #define SDM_K1_LB __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(SDM_K1_EU_MIN, 8)))
 #endif
-template <bool STATS>
+// MASK: the instantiation whose searches may take the scan over the gate bit planes (long ranges, sdm_device.h scan_masked);
+// the host launches it only for calls that have a pair with a long range at the principal point (stage_tables)
+template <bool STATS, bool MASK>
 __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long long plane,
                                                        const RefConst* __restrict__ refs,
                                                        const PairConst* __restrict__ pairs, int n_ref, int n,
                                                        int W, int H, int max_chunks, DevParams prm,
                                                        const unsigned* __restrict__ act, float2* __restrict__ pool,
                                                        unsigned long long* __restrict__ stats, OpenList open_list,
-                                                       const unsigned long long* __restrict__ gmask, int mrow)
+                                                       const unsigned* __restrict__ gmask, int mrow)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // [n][64] {rho, 1/sigma^2 (NaN = take the exact path)}: all a pair test reads; sigma itself is needed only by
@@ -421,7 +428,8 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
     }
     SearchStats st = {0, 0, 0};
     MaskStats ms = {0, 0, 0};
-    const unsigned mpitch = (unsigned)mrow << 3;  // bytes per row of a gradient-gate bit plane
+    MaskView mv;  // the neighbour's gate bit planes (sdm_device.h scan_masked); base per neighbour below
+    mv.row_pitch = (unsigned)mrow * MASK_WORD_BYTES;  // mrow: 32-bit words per image row
     const PairConst* __restrict__ pcs = pairs + (long long)ref * n;
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
     const float* __restrict__ rcv = rcvb;
@@ -449,9 +457,9 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         if (on) {
             float rho, sigma, bu, bv;
             const float* __restrict__ cv = reinterpret_cast<const float*>(pc);
-            const char* __restrict__ mb = reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * mrow);
-            bool ok = epipolar_search<STATS>(nrec, W, H, cv, rcv, pc->clean, true, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
-                                             sigma, bu, bv, &st, gmask ? mb : nullptr, mpitch, &ms);
+            mv.base = (MASK && gmask) ? reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * MASK_PLANES * mrow) : nullptr;
+            bool ok = epipolar_search<STATS, false, MASK>(nrec, W, H, cv, rcv, pc->clean, true, x, y, pixel, grad1, th_pi, xp0, xp1, prm, rho,
+                                             sigma, bu, bv, &st, mv, &ms);
             if (ok && __float_as_uint(rho) < 0x7f800000u) {  // PM.cc:216: 1/rho > 0  <=>  rho in [+0, +Inf) (denormals on)
                 h = make_float2(rho, sigma);
                 mymask |= 1ull << j;
@@ -1658,7 +1666,7 @@ __global__ __launch_bounds__(BLOCK) void k_pointset_list(const float* __restrict
 // ---- single-thread kernels behind the per-pixel C entry points ------------------------------------------------
 __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long plane, const RefConst* refs,
                                      const PairConst* pairs, int W, int H, int x, int y, DevParams prm,
-                                     float* __restrict__ out, const unsigned long long* __restrict__ gmask, int mrow)
+                                     float* __restrict__ out, const unsigned* __restrict__ gmask, int mrow)
 {
     const RefConst rc = refs[0];
     const PairConst* pc = pairs;
@@ -1672,9 +1680,11 @@ __global__ void k_epipolar_search_px(const float4* __restrict__ rec, long long p
     const float* cv = reinterpret_cast<const float*>(pc);
     const float rcvb[4] = {rc.fx, rc.cx, rc.mind, rc.maxd};
     MaskStats ms = {0, 0, 0};
-    const char* mb = reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * mrow);
-    bool ok = epipolar_search<false>(nrec, W, H, cv, rcvb, pc->clean, true, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma, bu, bv, &st,
-                                     gmask ? mb : nullptr, (unsigned)mrow << 3, &ms);
+    MaskView mv;
+    mv.base = gmask ? reinterpret_cast<const char*>(gmask + (long long)pc->nbr_slot * H * MASK_PLANES * mrow) : nullptr;
+    mv.row_pitch = (unsigned)mrow * MASK_WORD_BYTES;  // mrow: 32-bit words per image row
+    bool ok = epipolar_search<false, false, true>(nrec, W, H, cv, rcvb, pc->clean, true, x, y, pixel, r.x, r.y, xp0, xp1, prm, rho, sigma,
+                                                  bu, bv, &st, mv, &ms);
     out[0] = rho;
     out[1] = sigma;
     out[2] = ok ? 1.f : 0.f;

@@ -68,8 +68,10 @@ def test_long_ranges_all_scan_modes(pkg, oracle, gpu_ok, name, W, H, disp, pr, m
             assert st["mask_waves"] > 0
         if mode == 1:
             assert st["mask_waves"] == 0
-        if mode == 0 and min_mean >= 20:
+        if mode == 0 and min_mean >= 50:
             assert st["mask_waves"] > 0, "long ranges must reach the mask scan in the default mode"
+        if mode == 0 and min_mean == 0:
+            assert st["mask_waves"] == 0, "short ranges stay on the batched scan"
     assert sum(int((w[0] > 1e-6).sum()) for w in want) > 200, "the case must still fuse something"
 
 
@@ -131,3 +133,38 @@ def test_mask_plane_follows_lambdaG(pkg, oracle, gpu_ok):
         assert_bit_equal(gr, r, "lambdaG %g rho" % lam)
         assert_bit_equal(gs, s, "lambdaG %g sigma" % lam)
     eng.close()
+
+
+@pytest.mark.parametrize("lam_theta,lam_l", [(30.0, 80.0), (100.0, 70.0), (170.0, 80.0), (200.0, 85.0), (0.0, 80.0), (45.0, 80.0)])
+def test_mask_scan_other_thresholds(pkg, oracle, gpu_ok, lam_theta, lam_l):
+    """the orientation window the mask scan lists follows lambdaTheta (PM.h:38-49 made runtime): narrower, wider than the
+    planes resolve (falls back to the gradient plane), zero"""
+    from pm_oracle import Oracle
+    W, H, n_kf, n = 192, 96, 8, 7
+    seq = Sequence(pkg, oracle, W, H, n_kf, 0x5EED0A55, disparity_px=8.0)
+    mind, maxd = prior(1.0, 0.3)
+    o = Oracle("strict")
+    o.params.lambdaTheta = lam_theta
+    o.params.lambdaL = lam_l
+    refs = list(range(n_kf))
+    nbrs = [seq.neighbours(k, n) for k in refs]
+    rng = np.random.default_rng(5)
+    rots = rng.uniform(-20, 20, (n_kf, n)).astype(np.float32)
+    want = [o.recon_search_fuse(seq.okf[k], [seq.okf[j] for j in nbrs[k]], rots[k], mind, maxd) for k in refs]
+    for mode in (2, 0):
+        eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
+        seq.upload(eng, device_prepass=True)
+        eng.set_params(lambdaTheta=lam_theta, lambdaL=lam_l)
+        eng.set_scan_mode(mode)
+        eng.enable_stats(True)
+        eng.get_stats(reset=True)
+        eng.search_fuse(refs, nbrs, mind, maxd, rot=rots)
+        st = eng.get_stats()
+        for k in refs:
+            gr, gs = eng.download_depth(k)
+            assert_bit_equal(gr, want[k][0], "lambdaTheta %g mode %d rho kf %d" % (lam_theta, mode, k))
+            assert_bit_equal(gs, want[k][1], "lambdaTheta %g mode %d sigma kf %d" % (lam_theta, mode, k))
+        assert st["candidates"] == sum(w[2]["candidates"] for w in want)
+        assert st["gate_pass"] == sum(w[2]["gate_pass"] for w in want)
+        assert st["mask_row_mismatch"] == 0
+        eng.close()

@@ -52,7 +52,8 @@ sd = np.float32(spread) * mu
 maxd = float(np.float32(1) / (mu + np.float32(2) * sd))
 mind = float(np.float32(1) / (mu - np.float32(2) * sd))
 n = len(xs)
-acc = dict(waves=0, slots=0, p2_pass=0, p2_grad=0, steps_mask=0, L=0, ngrad=0, npass=0, lanes=0, absab=[], runs=0)
+NB_BINS = int(os.environ.get("NB_BINS", "6"))
+acc = dict(p2_bin=0, nbin=0, waves=0, slots=0, p2_pass=0, p2_grad=0, steps_mask=0, L=0, ngrad=0, npass=0, lanes=0, absab=[], runs=0)
 for j in nbrs:
     nb = make(j)
     pair = np_pm.Pair(ref, nb)
@@ -72,7 +73,9 @@ for j in nbrs:
     th_line = np_pm.fast_atan2_x1(-ab)
     apr = ref.theta[ys, xs]
     ngrad = np.zeros(n, np.int64)
+    nbin = np.zeros(n, np.int64)
     npass = np.zeros(n, np.int64)
+    b0 = np.floor(np.mod(apr - 45.0 - 0.01, 360.0) * (16.0 / 360.0)).astype(np.int64)
     rows_lo = np.zeros(n, np.int64)
     rows_hi = np.zeros(n, np.int64)
     for t in range(int(L.max())):
@@ -89,6 +92,8 @@ for j in nbrs:
         ok &= ~(nb.grad[vjc, ujc] < 8.0)
         ngrad += ok
         th2 = nb.theta[vjc, ujc]
+        bn = np.floor(th2 * (16.0 / 360.0)).astype(np.int64)
+        nbin += ok & (((bn - b0) & 15) < NB_BINS)
         d = np_pm._wrap_diff(th2 - th_line)
         d = np.where(d > 90, f32(180) - d, d)
         ok &= ~(d > 80)
@@ -107,10 +112,12 @@ for j in nbrs:
         acc["slots"] += (Lw + 3) // 4 * 4
         acc["p2_pass"] += int(npass[s].max())
         acc["p2_grad"] += int(ngrad[s].max())
+        acc["p2_bin"] += int(nbin[s].max())
         acc["steps_mask"] += int(steps[s].max())
     acc["L"] += int(L.sum())
     acc["ngrad"] += int(ngrad.sum())
     acc["npass"] += int(npass.sum())
+    acc["nbin"] += int(nbin.sum())
     acc["lanes"] += n
     acc["runs"] += int(runs.sum())
 w = acc["waves"]
@@ -122,6 +129,8 @@ print("per lane: L %.2f, gradient-gate pass %.2f (%.1f %%), all gates %.2f (%.1f
 print("|a/b|: median %.4f p90 %.4f p99 %.4f max %.4f" % tuple(np.percentile(absab, [50, 90, 99, 100])))
 print("per wave-search: slots now %.2f | defer-cost phase 2 iterations %.2f | grad-mask: mask steps %.2f, phase 2 iterations %.2f" % (
     acc["slots"] / w, acc["p2_pass"] / w, acc["steps_mask"] / w, acc["p2_grad"] / w))
+print("orientation bins (16 x 22.5 deg, %d from ang-45): listed per lane %.2f, phase 2 iterations per wave-search %.2f" % (
+    NB_BINS, acc["nbin"] / acc["lanes"], acc["p2_bin"] / w))
 # instruction model (wave-instructions per wave-search; EXPERIMENTS.md: skeleton ~15, gates ~17, cost ~25 per slot)
 SK, GA, CO = 15, 17, 25
 now = acc["slots"] / w * (SK + GA + CO)

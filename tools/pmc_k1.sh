@@ -14,7 +14,7 @@ root, tag = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 for f in glob.glob(root + "/p[12]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_search_fuse<false>" in r["Kernel_Name"]:
+        if "k_search_fuse<false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 print(tag)

@@ -22,7 +22,7 @@ for k in sorted(agg):
 # "calibrate on your own access pattern": FETCH_SIZE tallies every request at 64 B, but K1's gathers
 # leave the L2 as 128-B requests, so bytes = 32*n32 + 64*n64 + 128*n128; writes likewise).
 import json
-k1 = [k for k in agg if "k_search_fuse<false>" in k]
+k1 = [k for k in agg if "k_search_fuse<false" in k]
 if k1:
     c = {n: (sum(v) / len(v)) for n, v in agg[k1[0]].items()}
     need = ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]

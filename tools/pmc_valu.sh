@@ -13,7 +13,7 @@ root, tag = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 for f in glob.glob(root + "/p1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_search_fuse<false>" in r["Kernel_Name"]:
+        if "k_search_fuse<false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(tag, " ".join("%s=%.1fM" % (k.replace("SQ_", ""), sum(v) / len(v) / 1e6) for k, v in sorted(agg.items())))
 PY
