@@ -234,6 +234,9 @@ private:
     int W_ = 0, H_ = 0;
     std::map<sdm::KeyFrame*, int> slots_;
     std::map<sdm::KeyFrame*, int> depth_on_device_;  /* 1 = the slot's depth map equals kf->depth_map_ */
+    std::map<sdm::KeyFrame*, float> map_lambdaG_;    /* lambdaG the keyframe's host map was reconstructed under: its support is
+                                                        that keyframe's pixel list for THAT threshold (PM.cc:201) */
+    float CurrentLambdaG() const;
     std::vector<sdm::KeyFrame*> slot_owner_;
     std::vector<unsigned long> slot_use_;
     unsigned long tick_ = 0;

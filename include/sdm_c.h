@@ -78,6 +78,7 @@ int sdm_create(sdm_ctx **out, const sdm_config *cfg); /* replaces ProbabilityMap
 void sdm_destroy(sdm_ctx *ctx);
 const char *sdm_last_error(void);
 int sdm_set_params(sdm_ctx *ctx, const sdm_params *p);
+int sdm_get_params(sdm_ctx *ctx, sdm_params *out); /* the parameters in force */
 int sdm_set_stream(sdm_ctx *ctx, void *hip_stream);
 int sdm_synchronize(sdm_ctx *ctx);
 int sdm_device_count(void); /* number of visible HIP devices, 0 if none; never initialises a context */
@@ -237,13 +238,15 @@ int sdm_allgather_finish(sdm_ctx *ctx, int n_fetch, const int *fetch_index, cons
  * sdm_comm_destroy resets the format to whole maps. */
 int sdm_exchange_compact(sdm_ctx *ctx, int entries_per_map);
 /* Every compact map carries its sender's list length and the 64-bit hash of its list; a receiver whose list of that
- * keyframe differs in either (its image differs from the sender's) leaves the destination plane as it is instead of scattering onto wrong pixels, and
- * counts the event.  *count = such maps since the last call (host-blocking; 0 on a healthy job). */
+ * keyframe differs in either (its image differs from the sender's) does not scatter the map -- it would land on wrong
+ * pixels -- and counts the event: a destination that already held a pipeline map keeps it; one that did not (an arbitrary
+ * map, e.g. from sdm_upload_depth) has been zeroed for the scatter and stays zero.  *count = such maps since the last call
+ * (host-blocking; 0 on a healthy job). */
 int sdm_exchange_mismatches(sdm_ctx *ctx, int *count);
 /* The compact wire format through host memory, one map per call (host-blocking): the payload the RCCL forms would send
  * for `slot` -> out[2 * (entries_per_map + 8)] floats ({rho,sigma} of the list entries, then the header: list length
  * and hash), and the receiving side for a payload that travelled by another route (*refused = 1: packed with another
- * list; the slot's plane is left alone).  Same kernels and checks as sdm_exchange_* -- for transports the engine does not
+ * list; checked on the host before anything is written: the slot's plane is left alone).  Same kernels and checks as sdm_exchange_* -- for transports the engine does not
  * drive (a host framework's own, or gloo on a one-GPU box: shard.py). */
 int sdm_compact_pack_host(sdm_ctx *ctx, int slot, float *out);
 int sdm_compact_unpack_host(sdm_ctx *ctx, int slot, const float *in, int *refused);

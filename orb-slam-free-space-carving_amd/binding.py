@@ -112,6 +112,7 @@ SYMBOLS = [
     ("sdm_enable_stats", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_stats", C.c_int, [_ctx, C.POINTER(Stats), C.c_int]),
     ("sdm_set_scan_mode", C.c_int, [_ctx, C.c_int]),
+    ("sdm_get_params", C.c_int, [_ctx, C.POINTER(Params)]),
     ("sdm_selftest", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_ulonglong)]),
     ("sdm_enable_timing", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_timing", C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
@@ -211,6 +212,11 @@ class Engine:
         for k, v in kw.items():
             setattr(p, k, v)
         self._check(self.lib.sdm_set_params(self.ctx, C.byref(p)))
+
+    def get_params(self):
+        p = Params()
+        self._check(self.lib.sdm_get_params(self.ctx, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Params._fields_}
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.sdm_set_stream(self.ctx, stream_ptr))

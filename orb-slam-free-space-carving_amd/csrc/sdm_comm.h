@@ -183,9 +183,15 @@ __global__ __launch_bounds__(BLOCK) void k_pack_lists(ListBatch b, const float2*
     }
     const unsigned* __restrict__ list = act + (long long)slot * plane;
     const float2* __restrict__ map = pool + (long long)slot * plane;
-    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n; t += gridDim.x * BLOCK) {
-        const unsigned xy = list[t];
-        out[t] = map[(int)(xy >> 16) * W + (int)(xy & 0xffffu)];
+    // the list's entries, then zeros up to `entries`: the payload is a function of the map alone (the NumPy statement of the
+    // format, shard.pack_compact, pads with zeros as well: byte-for-byte equal payloads)
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < entries; t += gridDim.x * BLOCK) {
+        float2 v = make_float2(0.f, 0.f);
+        if (t < n) {
+            const unsigned xy = list[t];
+            v = map[(int)(xy >> 16) * W + (int)(xy & 0xffffu)];
+        }
+        out[t] = v;
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_unpack_lists(ListBatch b, float2* __restrict__ pool, long long plane, int W,
@@ -751,6 +757,30 @@ int sdm_compact_unpack_host(sdm_ctx* c, int slot, const float* in, int* refused)
     if (c->xchg_entries <= 0) return fail(SDM_ESTATE, "sdm_exchange_compact(ctx, entries_per_map > 0) first");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if ((rc = ensure_xchg_buffers(c, 0, 1))) return rc;
+    {
+        // the payload's header is in host memory: a payload packed with another list is refused BEFORE the destination plane
+        // is touched (prepare_compact_destinations zeroes a plane that is not a pipeline map yet)
+        if (!(c->act_lambdaG[slot] == c->dprm.lambdaG) && (rc = build_active(c, slot))) return rc;
+        if ((rc = sync_counts(c))) return rc;
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, c->d_act_hash + slot, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const float* hdr = in + 2 * (size_t)c->xchg_entries;
+        int hn;
+        unsigned hlo, hhi;
+        memcpy(&hn, hdr, 4);
+        memcpy(&hlo, hdr + 1, 4);
+        memcpy(&hhi, hdr + 2, 4);
+        if (hn != c->h_act_count[slot] || hlo != (unsigned)h || hhi != (unsigned)(h >> 32)) {
+            const unsigned one = 1u;  // counted like a refusal on the RCCL path (sdm_exchange_mismatches)
+            unsigned cur = 0;
+            HIP_TRY(hipMemcpy(&cur, c->d_xchg_mismatch, sizeof(unsigned), hipMemcpyDeviceToHost));
+            cur += one;
+            HIP_TRY(hipMemcpy(c->d_xchg_mismatch, &cur, sizeof(unsigned), hipMemcpyHostToDevice));
+            *refused = 1;
+            return SDM_OK;
+        }
+    }
     if ((rc = prepare_compact_destinations(c, 1, &slot, c->stream))) return rc;
     unsigned before = 0, after = 0;
     HIP_TRY(hipMemcpyAsync(&before, c->d_xchg_mismatch, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));

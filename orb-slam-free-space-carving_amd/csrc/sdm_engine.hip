@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -381,12 +382,23 @@ size_t select_set(sdm_ctx* c, int si, int n_ref, size_t np)
 // -- every keyframe's list positions below 108 032 -- and the rest of every map kept what it held before
 // (tools/debug/unsliced_holes.py).  Every launch whose grid grows with the number of reference keyframes is therefore issued
 // in slices of reference keyframes: fn(first, count) launches one slice.
-// (SDM_MAX_DISPATCH_LOG2: debugging knob, read per call -- how the finding was reproduced.)
+// (SDM_MAX_DISPATCH_LOG2: debugging knob, read once per process; values above 31 -- how the finding was reproduced --
+// need a build with -DSDM_DEBUG_KNOBS: tools/debug/unsliced_*.py.)
 template <typename F>
 void for_ref_slices(int n_ref, long long blocks_per_ref, int threads, F&& fn)
 {
-    int lg = 31;
-    if (const char* e = getenv("SDM_MAX_DISPATCH_LOG2")) lg = std::max(20, std::min(40, atoi(e)));
+    // read once; above 31 only in SDM_DEBUG_KNOBS builds (beyond 2^32 work-items the launch silently runs a partial grid)
+    static const int lg = [] {
+        int v = 31;
+        if (const char* e = getenv("SDM_MAX_DISPATCH_LOG2")) {
+#ifdef SDM_DEBUG_KNOBS
+            v = std::max(20, std::min(40, atoi(e)));
+#else
+            v = std::max(20, std::min(31, atoi(e)));
+#endif
+        }
+        return v;
+    }();
     const long long max_blocks = (1ll << lg) / threads;
     const int per = (int)std::max<long long>(1, std::min<long long>(n_ref, max_blocks / std::max<long long>(blocks_per_ref, 1)));
     for (int first = 0; first < n_ref; first += per) fn(first, std::min(per, n_ref - first));
@@ -890,6 +902,13 @@ int sdm_set_params(sdm_ctx* c, const sdm_params* p)
     return SDM_OK;
 }
 
+int sdm_get_params(sdm_ctx* c, sdm_params* out)
+{
+    if (!c || !out) return fail(SDM_EINVAL, "null argument");
+    *out = c->prm;
+    return SDM_OK;
+}
+
 int sdm_set_stream(sdm_ctx* c, void* s)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
@@ -963,28 +982,42 @@ struct Stager {
         int m = 0;
         size_t bytes = 0;
     };
-    int nt = 1;
+    int nt = 1;  // threads that copy: the caller + the helpers that actually started
     std::vector<std::thread> th;
     std::vector<Plan> plans;
     std::vector<std::atomic<int> > done;
-    std::atomic<int> posted{0};
-    std::atomic<int> quit{0};
+    std::mutex mu;
+    std::condition_variable cv;  // helpers sleep here between chunks (the caller may sit in a HIP wait for a long time)
+    int posted = 0;              // guarded by mu
+    bool quit = false;           // guarded by mu
 
-    Stager(int threads, int chunks) : nt(std::max(1, threads)), plans((size_t)chunks), done((size_t)chunks)
+    // never throws: a helper that cannot be started (EAGAIN under a thread limit, out of memory) is simply not there, and the
+    // caller stages alone if none can -- this runs inside a C-ABI entry point
+    Stager(int threads, int chunks) noexcept
     {
-        for (auto& d : done) d.store(0);
-        for (int t = 1; t < nt; t++)
-            th.emplace_back([this, t] {
-                for (size_t k = 0; k < plans.size(); k++) {
-                    while (posted.load(std::memory_order_acquire) <= (int)k) {
-                        if (quit.load(std::memory_order_acquire)) return;
-                        std::this_thread::yield();
+        try {
+            plans.resize((size_t)chunks);
+            done = std::vector<std::atomic<int> >((size_t)chunks);
+            for (auto& d : done) d.store(0);
+            th.reserve((size_t)std::max(0, threads - 1));
+            for (int t = 1; t < threads; t++)
+                th.emplace_back([this, t] {
+                    for (size_t k = 0; k < plans.size(); k++) {
+                        {
+                            std::unique_lock<std::mutex> lock(mu);
+                            cv.wait(lock, [&] { return quit || posted > (int)k; });
+                            if (quit) return;
+                        }
+                        share(plans[k], t);  // nt is final before the first plan is posted
+                        done[k].fetch_add(1, std::memory_order_release);
                     }
-                    share(plans[k], t);
-                    done[k].fetch_add(1, std::memory_order_release);
-                }
-            });
+                });
+        } catch (...) {
+            // keep the helpers that did start (their indices are 1 .. th.size(): the loop stops at the first failure)
+        }
+        nt = 1 + (int)th.size();
     }
+    bool usable() const { return !plans.empty() && done.size() == plans.size(); }
     void share(const Plan& p, int t) const
     {
         for (int i = t; i < p.m; i += nt) memcpy(p.dst + (size_t)i * p.bytes, p.src[i], p.bytes);
@@ -992,19 +1025,33 @@ struct Stager {
     // chunk k (chunks are staged in order): returns when all of it is in the ring
     void stage(int k, uint8_t* dst, const uint8_t* const* src, int m, size_t bytes)
     {
-        plans[(size_t)k].dst = dst;
-        plans[(size_t)k].src = src;
-        plans[(size_t)k].m = m;
-        plans[(size_t)k].bytes = bytes;
-        posted.store(k + 1, std::memory_order_release);
-        share(plans[(size_t)k], 0);
-        while (done[(size_t)k].load(std::memory_order_acquire) < nt - 1) std::this_thread::yield();
+        Plan p;
+        p.dst = dst;
+        p.src = src;
+        p.m = m;
+        p.bytes = bytes;
+        if (!usable() || nt == 1) {  // no helpers (or the tables could not be allocated): this thread copies everything
+            for (int i = 0; i < m; i++) memcpy(dst + (size_t)i * bytes, src[i], bytes);
+            return;
+        }
+        plans[(size_t)k] = p;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            posted = k + 1;
+        }
+        cv.notify_all();
+        share(p, 0);
+        while (done[(size_t)k].load(std::memory_order_acquire) < nt - 1) std::this_thread::yield();  // (they copy as long as we did)
     }
     ~Stager()
     {
-        quit.store(1, std::memory_order_release);
-        posted.store((int)plans.size(), std::memory_order_release);  // chunks never staged (pinned sources, errors): empty plans
-        for (auto& x : th) x.join();
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto& x : th)
+            if (x.joinable()) x.join();
     }
 };
 
@@ -1036,9 +1083,12 @@ int ensure_src_buffers(sdm_ctx* c)
 // n keyframes from host memory (gray: q == nullptr, P bytes each; else interleaved frames of P * q->channels bytes) or
 // from device memory (on_device: gray only).  Chunk k+1's copies run on the upload stream while chunk k's pre-pass runs
 // on the compute stream.  Pinned host images are copied from where they lie; pageable ones go through the pinned ring.
-int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* images, bool on_device, const IngestParams* q,
+int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const* images, bool on_device, const IngestParams* q,
                   const float* K, const float* Tcw)
 {
+    static const bool dbg = getenv("SDM_DEBUG_INGEST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_entry = dbg ? now() : 0.0;
     int rc = check_batch_slots(c, n, slots);
     if (rc) return rc;
     if (n == 0) return SDM_OK;
@@ -1067,16 +1117,31 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
     // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
     // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
     const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
-    const bool dbg = getenv("SDM_DEBUG_INGEST_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tdbg[6] = {0, 0, 0, 0, 0, 0};
+    const double t_loop = dbg ? now() : 0.0;
+    // An error in the middle of a batch: copies that read the caller's pinned images may still be in flight -- they are awaited
+    // before the call returns (the promise "every caller buffer is free on return" holds on the error path too).  Slots of
+    // chunks that were already launched hold their new keyframes; the slots of the failing and the later chunks are reset
+    // (no keyframe): the call reports failure for the batch, sdm_upload_* can simply be repeated.
+    int failed_from = n;
+    auto bail = [&](int code) {
+        const std::string keep = g_err;
+        if (direct) (void)hipStreamSynchronize(cs);
+        for (int i = failed_from; i < n; i++) {
+            reset_slot_state(c, slots[i]);
+            c->h_meta[slots[i]].uploaded = 0;
+        }
+        g_err = keep;
+        return code;
+    };
     for (int i0 = 0, chunk = 0; i0 < n; i0 += cap, chunk++) {
         const int m = std::min(cap, n - i0);
+        failed_from = i0;
         const int b = c->ing_next;
         c->ing_next ^= 1;
         sdm_ctx::IngestBuf& B = c->ing[b];
         if (dbg) tdbg[0] = now();
-        if ((rc = ingest_acquire(c, b, cs))) return rc;
+        if ((rc = ingest_acquire(c, b, cs))) return bail(rc);
         if (dbg) tdbg[1] = now();
         uint8_t* d_dst = q ? B.d_src : B.d_img;
         uint8_t* h_dst = q ? B.h_src : B.h_ring;
@@ -1097,17 +1162,20 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
                 for (int i = 0; i < m;) {
                     int r = 1;
                     while (i + r < m && images[i0 + i + r] == images[i0 + i + r - 1] + bytes) r++;
-                    HIP_TRY(hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], (size_t)r * bytes, hipMemcpyHostToDevice, cs));
+                    if (hipMemcpyAsync(d_dst + (size_t)i * bytes, images[i0 + i], (size_t)r * bytes, hipMemcpyHostToDevice, cs) != hipSuccess)
+                        return bail(fail(SDM_EHIP, "hipMemcpyAsync (pinned image) failed"));
+                    direct = true;
                     i += r;
                 }
                 direct = true;
             } else {
                 stager.stage(chunk, h_dst, images + i0, m, bytes);
-                HIP_TRY(hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, cs));
+                if (hipMemcpyAsync(d_dst, h_dst, (size_t)m * bytes, hipMemcpyHostToDevice, cs) != hipSuccess)
+                    return bail(fail(SDM_EHIP, "hipMemcpyAsync (staged images) failed"));
             }
         }
         if (dbg) tdbg[2] = now();
-        if ((rc = ingest_publish(c, b, m, cs))) return rc;
+        if ((rc = ingest_publish(c, b, m, cs))) return bail(rc);
         if (dbg) tdbg[3] = now();
         for (int i = 0; i < m; i++) {
             const int slot = slots[i0 + i];
@@ -1115,9 +1183,9 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
             c->h_meta[slot] = B.h_items[i].meta;  // (I_stddev lives on the device only)
             c->act_lambdaG[slot] = c->dprm.lambdaG;
         }
-        if ((rc = ingest_launch(c, b, m, true, q))) return rc;
+        if ((rc = ingest_launch(c, b, m, true, q))) return bail(rc);
         if (dbg) tdbg[4] = now();
-        if ((rc = ingest_counts(c, m, slots + i0))) return rc;
+        if ((rc = ingest_counts(c, m, slots + i0))) return bail(rc);
         if (dbg) {
             tdbg[5] = now();
             if (tdbg[5] - tdbg[0] > 2.0)
@@ -1128,11 +1196,27 @@ int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* ima
     }
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
     // in place are awaited here (the pre-pass kernels are not)
+    const double t_tail = dbg ? now() : 0.0;
     if (direct && last >= 0) {
         HIP_TRY(hipEventSynchronize(c->ing[last].copied));
         c->ing[last].copied_pending = false;
     }
+    if (dbg && now() - t_entry > 2.0)
+        fprintf(stderr, "[sdm ingest] slow call (%d keyframes): set-up %.3f  chunks %.3f  final wait %.3f ms\n", n, t_loop - t_entry,
+                t_tail - t_loop, now() - t_tail);
     return SDM_OK;
+}
+
+int ingest_images(sdm_ctx* c, int n, const int* slots, const uint8_t* const* images, bool on_device, const IngestParams* q,
+                  const float* K, const float* Tcw)
+{
+    try {  // (std::vector / std::string allocations: nothing may escape a C-ABI entry point)
+        return ingest_images_impl(c, n, slots, images, on_device, q, K, Tcw);
+    } catch (const std::exception& e) {
+        return fail(SDM_EHIP, std::string("ingest: ") + e.what());
+    } catch (...) {
+        return fail(SDM_EHIP, "ingest: unknown exception");
+    }
 }
 
 int colour_order(int order, IngestParams& q)
@@ -1518,8 +1602,11 @@ int sdm_recon(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* nbr
     int rc = stage_tables(c, n_ref, ref_slots, n, nbr_slots, rot, mind, maxd, true);
     if (rc) return rc;
     if ((rc = launch_search_fuse(c, n_ref, n, ref_slots))) return rc;  // PM.cc:197-231
-    if (const char* e = getenv("SDM_DEBUG_SYNC_K1"))  // debugging knob (tools/debug/unsliced_vs_sliced.py)
-        if (atoi(e) == 1) HIP_TRY(hipStreamSynchronize(c->stream));
+    static const bool sync_k1 = [] {  // debugging knob (tools/debug/unsliced_vs_sliced.py), read once per process
+        const char* e = getenv("SDM_DEBUG_SYNC_K1");
+        return e && atoi(e) == 1;
+    }();
+    if (sync_k1) HIP_TRY(hipStreamSynchronize(c->stream));
     if ((rc = run_intra_lists(c, n_ref, ref_slots, true, true))) return rc;  // PM.cc:237-238
     for (int r = 0; r < n_ref; r++) {
         c->has_depth[ref_slots[r]] = 1;  // kf->semidense_flag_, PM.cc:244

@@ -8,6 +8,7 @@
 // reference mutates (depth_map_, depth_sigma_, SemiDensePointSets_, the flags).
 #include "sdm/ProbabilityMapping.h"
 
+#include <cmath>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -183,6 +184,7 @@ void ProbabilityMapping::Forget(sdm::KeyFrame* kf)
     slot_owner_[it->second] = nullptr;
     slot_use_[it->second] = 0;
     depth_on_device_.erase(kf);
+    map_lambdaG_.erase(kf);
     slots_.erase(it);
 }
 
@@ -190,6 +192,13 @@ void ProbabilityMapping::InvalidateDepth(sdm::KeyFrame* kf)
 {
     auto it = depth_on_device_.find(kf);
     if (it != depth_on_device_.end()) it->second = 0;
+}
+
+float ProbabilityMapping::CurrentLambdaG() const
+{
+    sdm_params p;
+    if (sdm_get_params(ctx_, &p) != SDM_OK) return std::nanf("");
+    return p.lambdaG;
 }
 
 // make the slot's depth map equal to the keyframe's host maps
@@ -260,6 +269,7 @@ void ProbabilityMapping::SemiDenseRecon(sdm::KeyFrame* kf)
         return;
     }
     depth_on_device_[kf] = 1;
+    map_lambdaG_[kf] = CurrentLambdaG();
     kf->semidense_flag_ = true;  // PM.cc:244
 
     // PM.cc:262-315
@@ -645,12 +655,22 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         // own keyframes reconstructed in an earlier pass answer with the map they have.  While the device slot still holds
         // that map nothing is touched (it stays a pipeline map the compact exchange accepts); a slot that was recycled gets
         // the host copy back -- the reconstructed or the checked map, both zero outside the keyframe's pixel list
-        // (PM.cc:201, 662) -- and is declared a pipeline map again.  A keyframe without a map is never marked: nobody's
-        // plan reads it (PlanBlock)
+        // (PM.cc:201, 662) -- and is declared a pipeline map again, PROVIDED it was reconstructed under the lambdaG in force
+        // now: under another threshold its support can lie outside the list the declaration rebuilds, and the list kernels and
+        // the compact send would drop those pixels.  Such a map stays an ordinary map; the pass then moves whole maps (the
+        // compact-source question below answers no).  A keyframe without a map is never marked: nobody's plan reads it
+        // (PlanBlock)
+        const float lam_now = CurrentLambdaG();
         for (int i = first; i < first + count && local_ok; i++) {
             if (!all[i]->semidense_flag_ || depth_on_device_[all[i]]) continue;
             PushDepth(all[i], slot[i]);
-            if (!depth_on_device_[all[i]] || sdm_assume_pipeline_maps(ctx_, 1, &slot[i]) != SDM_OK) {
+            if (!depth_on_device_[all[i]]) {
+                report("SemiDenseReconBlock");
+                local_ok = false;
+                continue;
+            }
+            auto it = map_lambdaG_.find(all[i]);
+            if (it != map_lambdaG_.end() && it->second == lam_now && sdm_assume_pipeline_maps(ctx_, 1, &slot[i]) != SDM_OK) {
                 report("SemiDenseReconBlock");
                 local_ok = false;
             }
@@ -802,6 +822,7 @@ void ProbabilityMapping::SemiDenseReconBlock(const std::vector<sdm::KeyFrame*>& 
         sdm::KeyFrame* kf = all[refs[a]];
         if (sdm_download_depth(ctx_, slot[refs[a]], kf->depth_map_.ptr(), kf->depth_sigma_.ptr()) != SDM_OK) report("SemiDenseReconBlock");
         depth_on_device_[kf] = 1;
+        map_lambdaG_[kf] = CurrentLambdaG();
         kf->semidense_flag_ = true;
     }
     for (size_t a = 0; a < plan.check.size(); a++) {

@@ -337,7 +337,13 @@ def allgather_boundary_compact(codec, pl, group=None):
     """torch transport, compact payloads staged through host memory: the boundary all-gather"""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    mine = torch.stack([codec.pack(s) for s in contrib_slots(pl)])
+    # real contributions are packed; padding positions (a rank with fewer boundary keyframes than the common count, or none)
+    # carry a zero payload -- nobody fetches them, and packing a real slot there would fail on a rank whose padding slot is not
+    # reconstructed yet while its peers already sit in the all-gather
+    real = [pl["slot"][k] for k in pl["contrib"][pl["rank"]]]
+    packed = [codec.pack(s) for s in real]
+    zero = torch.zeros((codec.entries + XCHG_HEADER, 2), dtype=torch.float32)
+    mine = torch.stack(packed + [zero] * (pl["contrib_count"] - len(packed)))
     gather = torch.empty((pl["world"] * pl["contrib_count"],) + tuple(mine.shape[1:]), dtype=torch.float32)
     dist.all_gather_into_tensor(gather, mine, group=group)
     for i, s in contrib_fetch_list(pl):

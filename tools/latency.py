@@ -25,6 +25,13 @@ min_d, max_d = scene.depth_prior()
 nb = {k: scene.neighbours(k, n_kf, N) for k in range(n_kf)}
 eng.recon(list(range(n_kf)), [nb[k] for k in range(n_kf)], min_d, max_d)  # everything reconstructed once
 eng.synchronize()
+# The timed loops run with Python's cyclic garbage collector off: a full (generation 2) collection of this interpreter's heap --
+# torch is loaded -- takes ~40 ms and lands deterministically after a few hundred binding calls; round 4's "p99 25 ms" of the
+# single-keyframe upload was exactly one such collection inside its 50 samples (tools/debug/upload_spikes2.py: the engine's own
+# whole-call timer stays below 2 ms for that call, and the outlier disappears with gc.disable()).  A C++ caller has no such pause.
+import gc
+gc.collect()
+gc.disable()
 t_recon, t_rest = [], []
 for rep in range(3):
     for k in range(n_kf):
