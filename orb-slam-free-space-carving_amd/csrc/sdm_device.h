@@ -61,6 +61,15 @@ struct DevParams {  // sdm_params + host-precomputed (1/THETA), PM.cc:455-456
     double inv_theta;
     int fast_theta_div;  // x/theta_var via reciprocal + FMA correction (exhaustively verified for 0.23)
     int default_gates;   // lambdaL == 80 && lambdaTheta == 45: the closed-form angle gates apply
+    // the scan's closed-form gates and approximate arg-min cost for thresholds OTHER than the defaults (the default ones are
+    // literals in the code): constants derived on the host, each form checked on the device against the reference statement
+    // for exactly these values when the parameters are set (sdm_set_params -> validate_params)
+    float g2c;            // gate 2 fails  <=>  ||x-180| - 90| < g2c          (g2c = 90 - lambdaL rounded up; 10 for the default)
+    unsigned g3lo, g3span;  // gate 3 fails  <=>  bits(x) - g3lo < g3span       (bits in (lambdaTheta, 360 - lambdaTheta))
+    float inv_theta_f;    // (float)(1 / theta_var)
+    int closed_ok;        // the two closed forms agree with PM.cc:416-431 for every d in [-400, 360): use them
+    int approx_ok;        // fma(ge2, inv_theta_f, pe2) stays within COST_BAND / 4 steps of PM.cc:436: the arg-min may compare it
+    int bins_ok;          // 0 <= lambdaTheta <= MASK_MAX_LAMBDA_THETA: the mask scan's six orientation planes hold the window
     int scan_mode;       // K1's scan per (wave, neighbour): 0 = chosen from the wave's range lengths and line slopes,
                          // 1 = always the batched scan, 2 = always the gradient-mask scan (tests; SDM_SCAN_MODE)
 };
@@ -302,6 +311,17 @@ __device__ __forceinline__ bool gate3_fails_fast(float d)
 //   gate 3: 45 < x < 315 as an unsigned range test on the bit pattern (x is never negative after the wrap when d >= -360;
 //           a negative or NaN x lands above the range: not "fails", like the float comparisons).
 // sdm_selftest(3) compares these forms, too, with the reference statement over every float in [-400,400].
+// the same forms with run-time constants (DevParams::g2c, g3lo, g3span): thresholds other than the defaults
+__device__ __forceinline__ bool gate2_fails_k(float d, float g2c)
+{
+    const float x = wrap_neg360(d);
+    return fabsf(fabsf(x - 180.0f) - 90.0f) < g2c;
+}
+__device__ __forceinline__ bool gate3_fails_k(float d, unsigned g3lo, unsigned g3span)
+{
+    const float x = wrap_neg360(d);
+    return (__float_as_uint(x) - g3lo) < g3span;
+}
 __device__ __forceinline__ bool gate2_fails_fast1(float d)
 {
     const float x = wrap_neg360(d);
@@ -641,12 +661,17 @@ __device__ __forceinline__ void scan_candidate(const ScanConst& q, int uj, float
 #endif
     const float d2 = r.y - q.th_line;     // PM.cc:415-416
     const float d3 = r.y - q.ang_pi_rot;  // PM.cc:427
+    bool fail;
+    if (CLEAN) {
 #if SDM_K1_OPT & 0x04
-    bool fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
+        fail = gate2_fails_fast1(d2) | gate3_fails_fast1(d3);
 #else
-    bool fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
+        fail = gate2_fails_fast(d2) | gate3_fails_fast(d3);
 #endif
-    if (!CLEAN) {
+    } else {
+        // the constants of the thresholds in force; gate_lim = 360 where they were validated (else -Inf: every candidate
+        // takes the reference statement), and an angle pair outside the closed forms' domain takes it too
+        fail = gate2_fails_k(d2, prm.g2c) | gate3_fails_k(d3, prm.g3lo, prm.g3span);
         if (__builtin_expect(!((d2 < q.gate_lim) & (d3 < q.gate_lim)), 0))
             fail = gate2_fails_ref(d2, prm.lambdaL) || gate3_fails_ref(d3, prm.lambdaTheta);
     }
@@ -660,9 +685,9 @@ __device__ __forceinline__ void scan_candidate(const ScanConst& q, int uj, float
     float pe = q.pixel - rec_lerp_im_w(r, y0w);        // PM.cc:433
     float ge = q.grad1 - rec_lerp_grad_w(r, y0w);      // PM.cc:434
 #if SDM_K1_OPT & 0x2000
-    if (CLEAN) {  // (this instantiation also implies theta_var == 0.23)
+    if (CLEAN || prm.approx_ok) {  // (CLEAN implies theta_var == 0.23: the literal; otherwise wave-uniform)
         // S.old_err holds the APPROXIMATE cost of the best candidate so far (1e6 exactly before the first)
-        const float e = match_cost_approx(pe * pe, ge * ge);
+        const float e = CLEAN ? match_cost_approx(pe * pe, ge * ge) : __builtin_fmaf(ge * ge, prm.inv_theta_f, pe * pe);
         bool better = e < S.old_err;
         if (__builtin_expect((__float_as_uint(e) - __float_as_uint(S.old_err) + COST_BAND) <= 2u * COST_BAND, 0))
             better = match_cost_ref(pe * pe, ge * ge, prm) < match_cost_ref(S.best_pe * S.best_pe, S.best_ge * S.best_ge, prm);
@@ -764,8 +789,8 @@ __device__ __forceinline__ void scan_segment(const ScanConst& q, int lo, const D
 //     reference's wrap, PM.cc:428-431; its float roundings move d by < 1e-4).  bin(t) = min(floor(t * 16/360), 15) in float is
 //     weakly monotone in t, so the bins bin(lo) .. bin(hi) of a window [lo, hi] hold every angle inside it, whatever the
 //     rounding at bin edges; the window is widened by MASK_ANG_MARGIN on both sides: at most MASK_WINDOW = 6 bins for the
-//     default lambdaTheta = 45.  Pairs that are not "clean" (an angle outside [0,360], PairConst::clean) and other thresholds
-//     use the union plane; pixels whose angle is outside [0,360) (caller-supplied planes only) sit in every plane.
+//     default lambdaTheta = 45 and for any threshold up to MASK_MAX_LAMBDA_THETA.  Pairs that are not "clean" (an angle
+//     outside [0,360], PairConst::clean) and wider thresholds use the union plane; pixels whose angle is outside [0,360) (caller-supplied planes only) sit in every plane.
 //   * rows: the candidates uj = u .. u+n of a lane lie in ONE row when n is small enough:  yf(uj) = -((a/b)*uj + c/b) as computed
 //     in float is weakly monotone in uj (a product and a sum by constants, each rounded to nearest: rounding is monotone) and
 //     stays within E of the real line through the float values a/b, c/b -- E < 2^-11 + 2^-9 for |a/b| <= 4, uj < 2^14,
@@ -803,6 +828,9 @@ constexpr int MASK_HINT_L = SDM_MASK_MIN_L * 3 / 4;  // PairConst::clean bit 2
 #endif
 constexpr int MASK_CALL_MEAN_L = SDM_MASK_CALL_MEAN_L;
 constexpr float MASK_ANG_MARGIN = 0.01f;
+// six consecutive bins from the one the window starts in cover at least 5 * 22.5 degrees from the window's start: windows of
+// 2 * (lambdaTheta + margin) <= 112.5 degrees
+constexpr float MASK_MAX_LAMBDA_THETA = 56.0f;
 constexpr float MASK_BIN_SCALE = (float)MASK_BINS / 360.0f;
 // the bin of an angle in [0,360): weakly monotone in t (product by a constant, floor, min)
 __host__ __device__ __forceinline__ int mask_bin(float t)
@@ -828,7 +856,7 @@ __device__ __forceinline__ void scan_masked(const ScanConst& q, const MaskView& 
     // the first plane of the lane's window as a byte offset inside a word's planes (BINNED: ang is in [0,360))
     unsigned pl0 = 4u * (unsigned)MASK_UNION;
     if (BINNED) {
-        float w0 = q.ang_pi_rot - (45.0f + MASK_ANG_MARGIN);
+        float w0 = q.ang_pi_rot - (prm.lambdaTheta + MASK_ANG_MARGIN);
         if (w0 < 0.0f) w0 += 360.0f;
         pl0 = 4u * (unsigned)mask_bin(w0);
     }
@@ -1026,7 +1054,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 
     // closed-form gates need d < 360 and the default thresholds; with other thresholds the limit is -Inf and
     // every candidate takes the reference statement (a float limit keeps the test free of a uniform-bool VGPR)
-    const float gate_lim = prm.default_gates ? 360.0f : -__builtin_inff();
+    const float gate_lim = prm.closed_ok ? 360.0f : -__builtin_inff();
     // "no candidate yet": cost 1e6 (PM.cc:396) -- pe = 1000, ge = 0 ARE that cost under the exact statement, which is what the
     // approximate arg-min (bit 13) evaluates when its first near-tie involves the initial state; best_pixel = -1 marks it
     ScanState S = {1000000.0f, 1000.0f, 0.f, -1};
@@ -1078,7 +1106,7 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
         if (MASK && mv.base != nullptr && prm.scan_mode != 1 && ((clean & 4) || prm.scan_mode == 2)) {
             // the orientation window needs ang in [0,360) -- a clean pair -- and the default thresholds the planes are cut for;
             // the gradient plane alone pays later
-            const bool binned = (clean & 1) && prm.default_gates && prm.fast_theta_div && SDM_MASK_BINS;
+            const bool binned = (clean & 1) && prm.bins_ok && SDM_MASK_BINS;
             const int min_l = binned ? SDM_MASK_MIN_L : SDM_MASK_MIN_L_UNION;
             const unsigned long long lng = __builtin_amdgcn_ballot_w64(hi - lo + 1 >= min_l);
             const unsigned long long steep = __builtin_amdgcn_ballot_w64(fabsf(ab) > SDM_MASK_MAX_SLOPE);
@@ -1087,12 +1115,15 @@ __device__ __forceinline__ bool epipolar_search(const float4* __restrict__ nrec,
 #endif
         if (MASK && masked) {
             if (STATS && (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__builtin_ctzll(here)) ms->waves++;
-            // the orientation window needs ang in [0,360) -- a clean pair -- and the default lambdaTheta the planes are cut for
+            // the orientation window needs ang in [0,360) -- a clean pair -- and a lambdaTheta whose window six planes hold
 #if SDM_K1_OPT & 0x02
             if ((clean & 1) && prm.default_gates && prm.fast_theta_div)  // wave-uniform
                 scan_masked<STATS, true, SDM_MASK_BINS != 0>(sc, mv, lo, prm, S, st, ms);
             else
 #endif
+                if ((clean & 1) && prm.bins_ok && SDM_MASK_BINS)
+                scan_masked<STATS, false, true>(sc, mv, lo, prm, S, st, ms);
+            else
                 scan_masked<STATS, false, false>(sc, mv, lo, prm, S, st, ms);
         } else {
 #if SDM_K1_OPT & 0x02

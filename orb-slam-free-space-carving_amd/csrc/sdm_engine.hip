@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -125,6 +126,9 @@ struct sdm_ctx {
     int mrow = 0;                              // 32-bit words per image row: 2 * (tiles_x + 1) (the last two stay zero: the scan
                                                // reads the word after the one a column lies in)
     int scan_mode = 0;                         // DevParams::scan_mode (SDM_SCAN_MODE, read once in sdm_create)
+    bool validated = false;                    // validate_params: the last non-default parameter set checked on the device ...
+    sdm_params validated_prm{};
+    int validated_closed = 0, validated_approx = 0;  // ... and what held for it
     float* d_grad = nullptr;
     float* d_theta = nullptr;
     float* d_small = nullptr;  // 16 floats of per-pixel results
@@ -218,6 +222,66 @@ void set_dev_params(sdm_ctx* c)
     c->dprm.fast_theta_div = (c->prm.theta_var == 0.23) ? 1 : 0;
     c->dprm.default_gates = (c->prm.lambdaL == 80.0f && c->prm.lambdaTheta == 45.0f) ? 1 : 0;
     c->dprm.scan_mode = c->scan_mode;
+    // constants of the closed-form gates for the thresholds in force (sdm_device.h gate2_fails_k / gate3_fails_k): the real
+    // bounds 90 - lambdaL and 360 - lambdaTheta are exact in double; a float compared with "<" against a real bound is
+    // compared against the smallest float at or above it.  Whether the forms hold for these values is decided on the device
+    // (validate_params), not here.
+    auto round_up = [](double v) {
+        float f = (float)v;
+        if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        return f;
+    };
+    const float lL = c->prm.lambdaL, lT = c->prm.lambdaTheta;
+    c->dprm.g2c = (lL == lL) ? round_up(90.0 - (double)lL) : 0.0f;  // (NaN: "d > NaN" never fails)
+    if (lT >= 0.0f && lT < 180.0f) {
+        unsigned lo, hi;
+        const float t_up = round_up(360.0 - (double)lT);
+        memcpy(&lo, &lT, 4);
+        memcpy(&hi, &t_up, 4);
+        c->dprm.g3lo = lo + 1u;
+        c->dprm.g3span = hi - (lo + 1u);
+    } else if (lT < 0.0f) {  // every non-NaN distance exceeds a negative threshold
+        c->dprm.g3lo = 0u;
+        c->dprm.g3span = 0x7F800001u;
+    } else {  // >= 180 or NaN: nothing fails
+        c->dprm.g3lo = 0u;
+        c->dprm.g3span = 0u;
+    }
+    c->dprm.inv_theta_f = (float)(1.0 / c->prm.theta_var);
+    c->dprm.bins_ok = (lT >= 0.0f && lT <= MASK_MAX_LAMBDA_THETA) ? 1 : 0;
+    const bool defaults = c->dprm.default_gates && c->dprm.fast_theta_div;
+    c->dprm.closed_ok = c->dprm.default_gates;  // the defaults are covered by sdm_selftest(3); anything else: validate_params
+    c->dprm.approx_ok = defaults ? 1 : 0;
+}
+
+// Thresholds other than the defaults: run the two device self-tests for exactly these values -- every float d in [-400, 360)
+// through both gate forms, and the sampled distance between the approximate and the reference matching cost -- and switch
+// the closed forms / the approximate arg-min on only if they hold (a few milliseconds, once per distinct parameter set).
+int validate_params(sdm_ctx* c)
+{
+    if (c->dprm.default_gates && c->dprm.fast_theta_div) return SDM_OK;
+    if (c->validated && memcmp(&c->validated_prm, &c->prm, sizeof(sdm_params)) == 0) {
+        c->dprm.closed_ok = c->validated_closed;
+        c->dprm.approx_ok = c->validated_approx;
+        return SDM_OK;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    unsigned long long out[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->dprm, c->d_stats + 4, c->d_stats + 5);
+    hipLaunchKernelGGL(k_selftest_cost, dim3(256), dim3(BLOCK), 0, c->stream, c->dprm, 256, c->d_stats + 6, c->d_stats + 7);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->d_stats + 4, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double th = c->prm.theta_var;
+    c->validated_closed = (out[0] == 0 && out[1] > 0) ? 1 : 0;
+    c->validated_approx = (out[2] == 0 && th >= 1.0e-6 && th <= 1.0e6) ? 1 : 0;
+    c->validated_prm = c->prm;
+    c->validated = true;
+    c->dprm.closed_ok = c->validated_closed;
+    c->dprm.approx_ok = c->validated_approx;
+    return SDM_OK;
 }
 
 int blocks_for(long long n) { return (int)((n + BLOCK - 1) / BLOCK); }
@@ -899,7 +963,7 @@ int sdm_set_params(sdm_ctx* c, const sdm_params* p)
     if (!(p->theta_var > 0) || p->lambdaN < 0) return fail(SDM_EINVAL, "bad parameter value");
     c->prm = *p;
     set_dev_params(c);
-    return SDM_OK;
+    return validate_params(c);
 }
 
 int sdm_get_params(sdm_ctx* c, sdm_params* out)
@@ -2038,7 +2102,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     } else if (which == 8) {
         hipLaunchKernelGGL(k_selftest_scan_ids, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
     } else if (which == 3) {
-        hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
+        hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->dprm, c->d_stats + 5, c->d_stats + 6);
     } else {
         return fail(SDM_EINVAL, "unknown selftest");
     }

@@ -1997,6 +1997,13 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_cost(DevParams prm, int iter
             if (r1 == r1 && d1 > COST_BAND / 2u) cnt++;
             if (ref == ref && d2 > COST_BAND / 2u) cnt++;
         }
+        {  // ... and the same with the run-time constant of the theta_var in force (DevParams::inv_theta_f / approx_ok)
+            const float r1 = (float)((double)pe2 + (double)ge2 / prm.theta_var);
+            const unsigned d1 = __float_as_uint(__builtin_fmaf(ge2, prm.inv_theta_f, pe2)) - __float_as_uint(r1) + COST_BAND / 4u;
+            const unsigned d2 = __float_as_uint(__builtin_fmaf(ge2s, prm.inv_theta_f, pe2s)) - __float_as_uint(ref) + COST_BAND / 4u;
+            if (r1 == r1 && d1 > COST_BAND / 2u) cnt++;
+            if (ref == ref && d2 > COST_BAND / 2u) cnt++;
+        }
         double sfast = (double)pe2 + (double)ge2 * prm.inv_theta;
         unsigned lo = (unsigned)__double2loint(sfast);
         if (((lo & 0x1FFFFFFFu) - 0x0FFFFF00u) <= 0x200u) hits++;
@@ -2091,17 +2098,23 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_quot(int iters, unsigned lon
 // which = 3: closed-form angle gates vs the reference statement, for d = theta2 - ref over
 // (a) every float in [-400, 400] visited with a stride, (b) every float within 64 ulps of each
 // boundary (+-45, +-80, +-100, +-260, +-280, +-315, 0, +-180, +-360), (c) random theta pairs.
-__global__ __launch_bounds__(BLOCK) void k_selftest_gates(unsigned long long* __restrict__ bad,
+// With prm: also the run-time-constant forms (gate2_fails_k / gate3_fails_k) against the reference statement under
+// prm.lambdaL / prm.lambdaTheta -- how sdm_set_params decides whether thresholds other than the defaults may use them.
+__global__ __launch_bounds__(BLOCK) void k_selftest_gates(DevParams prm, unsigned long long* __restrict__ bad,
                                                           unsigned long long* __restrict__ tested)
 {
     const unsigned gid = blockIdx.x * BLOCK + threadIdx.x, nthreads = gridDim.x * BLOCK;
     unsigned long long cnt = 0, n = 0;
     auto check = [&](float d) {
         if (!(d < 360.0f)) return;  // the kernel's guard routes these to the reference form
-        if (gate2_fails_fast(d) != gate2_fails_ref(d, 80.0f)) cnt++;
-        if (gate3_fails_fast(d) != gate3_fails_ref(d, 45.0f)) cnt++;
-        if (gate2_fails_fast1(d) != gate2_fails_ref(d, 80.0f)) cnt++;  // the one-comparison forms the scan uses
-        if (gate3_fails_fast1(d) != gate3_fails_ref(d, 45.0f)) cnt++;
+        if (prm.default_gates) {
+            if (gate2_fails_fast(d) != gate2_fails_ref(d, 80.0f)) cnt++;
+            if (gate3_fails_fast(d) != gate3_fails_ref(d, 45.0f)) cnt++;
+            if (gate2_fails_fast1(d) != gate2_fails_ref(d, 80.0f)) cnt++;  // the one-comparison forms the scan uses
+            if (gate3_fails_fast1(d) != gate3_fails_ref(d, 45.0f)) cnt++;
+        }
+        if (gate2_fails_k(d, prm.g2c) != gate2_fails_ref(d, prm.lambdaL)) cnt++;
+        if (gate3_fails_k(d, prm.g3lo, prm.g3span) != gate3_fails_ref(d, prm.lambdaTheta)) cnt++;
         n++;
     };
     // (a) strided sweep of the positive and negative float line up to |d| = 400 (0x43C80000)
@@ -2109,7 +2122,7 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_gates(unsigned long long* __
         check(__uint_as_float(u));
         check(__uint_as_float(u | 0x80000000u));
     }
-    // (b) boundary neighbourhoods
+    // (b) boundary neighbourhoods (the sweep above visits every float; these are the named places once more)
     const float bnd[12] = {0.f, 45.f, 80.f, 90.f, 100.f, 180.f, 260.f, 270.f, 280.f, 315.f, 360.f, 135.f};
     if (gid < 12 * 4096) {
         unsigned base = __float_as_uint(bnd[gid / 4096]);

@@ -135,10 +135,13 @@ def test_mask_plane_follows_lambdaG(pkg, oracle, gpu_ok):
     eng.close()
 
 
-@pytest.mark.parametrize("lam_theta,lam_l", [(30.0, 80.0), (100.0, 70.0), (170.0, 80.0), (200.0, 85.0), (0.0, 80.0), (45.0, 80.0)])
-def test_mask_scan_other_thresholds(pkg, oracle, gpu_ok, lam_theta, lam_l):
-    """the orientation window the mask scan lists follows lambdaTheta (PM.h:38-49 made runtime): narrower, wider than the
-    planes resolve (falls back to the gradient plane), zero"""
+@pytest.mark.parametrize("lam_theta,lam_l,theta_var", [(30.0, 80.0, 0.23), (100.0, 70.0, 0.25), (170.0, 80.0, 0.23),
+                                                        (200.0, 85.0, 0.1), (0.0, 80.0, 0.23), (45.0, 80.0, 0.25),
+                                                        (40.0, 70.0, 0.25), (56.0, 95.0, 3.0), (-5.0, -1.0, 0.23)])
+def test_other_thresholds_all_scan_modes(pkg, oracle, gpu_ok, lam_theta, lam_l, theta_var):
+    """PM.h:38-49 made runtime: thresholds other than the defaults run the closed-form gates and the approximate arg-min
+    with run-time constants (validated on the device when they are set, sdm_set_params), and the orientation window the
+    mask scan lists follows lambdaTheta: narrower, wider than the planes resolve (the gradient plane alone), zero, negative"""
     from pm_oracle import Oracle
     W, H, n_kf, n = 192, 96, 8, 7
     seq = Sequence(pkg, oracle, W, H, n_kf, 0x5EED0A55, disparity_px=8.0)
@@ -146,15 +149,16 @@ def test_mask_scan_other_thresholds(pkg, oracle, gpu_ok, lam_theta, lam_l):
     o = Oracle("strict")
     o.params.lambdaTheta = lam_theta
     o.params.lambdaL = lam_l
+    o.params.theta_var = theta_var
     refs = list(range(n_kf))
     nbrs = [seq.neighbours(k, n) for k in refs]
     rng = np.random.default_rng(5)
     rots = rng.uniform(-20, 20, (n_kf, n)).astype(np.float32)
     want = [o.recon_search_fuse(seq.okf[k], [seq.okf[j] for j in nbrs[k]], rots[k], mind, maxd) for k in refs]
-    for mode in (2, 0):
+    for mode in (2, 0, 1):
         eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
         seq.upload(eng, device_prepass=True)
-        eng.set_params(lambdaTheta=lam_theta, lambdaL=lam_l)
+        eng.set_params(lambdaTheta=lam_theta, lambdaL=lam_l, theta_var=theta_var)
         eng.set_scan_mode(mode)
         eng.enable_stats(True)
         eng.get_stats(reset=True)

@@ -19,6 +19,10 @@ ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--disparity", type=float, default=2.6)
 ap.add_argument("--spread", type=float, default=0.1, help="depth prior s = spread * mu (PM.cc:381-382)")
 ap.add_argument("--scan-mode", type=int, default=-1, help="sdm_set_scan_mode: 0 per wave, 1 batched, 2 gradient mask")
+ap.add_argument("--params", default="", help="sdm_set_params overrides, e.g. lambdaL=70,lambdaTheta=40,theta_var=0.25")
+ap.add_argument("--theta360", action="store_true",
+                help="keyframes uploaded as planes (sdm_upload_keyframe) with GradTheta = 360.0 at some pixels: pairs are not "
+                     "'clean' (PairConst::clean), the scan keeps the per-candidate precondition of the closed-form gates")
 ap.add_argument("--check", action="store_true", help="compare K1 maps with the default library's (bit-exact)")
 ap.add_argument("--outliers", type=int, default=0,
                 help="replace this many of every keyframe's neighbours by a copy with a wrong pose (baseline stretched by "
@@ -30,6 +34,19 @@ wl = bench.Workload(pkg, torch, a.res, a.kfs, a.nbrs, a.disparity, 1, 0, 0, nois
 eng, pl = wl.eng, wl.pl
 if a.scan_mode >= 0:
     eng.set_scan_mode(a.scan_mode)
+if a.theta360:
+    import numpy as np
+    for k in pl["inputs"]:
+        im, g, th, istd = eng.download_inputs(pl["slot"][k])
+        th = th.copy()
+        th[::7, ::5] = np.float32(360.0)
+        eng.upload_keyframe(pl["slot"][k], im, g, th, istd, wl.K, wl.scene.Tcw(k))
+if a.params:
+    kw = {}
+    for item in a.params.split(","):
+        k_, v_ = item.split("=")
+        kw[k_] = int(v_) if k_ == "lambdaN" else float(v_)
+    eng.set_params(**kw)
 if a.outliers:
     # a second engine with kfs extra slots holding wrong-pose copies; neighbour j of keyframe k at list position
     # 3, 7, 11, ... is redirected to the copy of j
