@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--prior-spread", type=float, default=0.1,
                     help="depth prior of StereoSearchConstraints (PM.cc:381-382): s = spread * mu (App. D: 0.1; ORB depths of "
                          "a real keyframe spread 0.3-0.5) -- the other scan-length knob")
+    ap.add_argument("--scene", default="plane", choices=["plane", "strip"],
+                    help="strip: App. D's second plane -- a foreground strip with occluding edges (depth discontinuities)")
+    ap.add_argument("--roll", type=float, default=1.0,
+                    help="keyframes' in-plane roll drawn from [-roll, roll] degrees (App. D: 1); above 1 the pairs carry the "
+                         "matching median in-plane rotation of PM.cc:170-179")
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
@@ -118,7 +123,7 @@ class Workload:
     """One resident workload on this rank: scene, plan, engine, uploaded keyframes."""
 
     def __init__(self, pkg, torch, res, kfs, N, disparity, world, rank, local_rank, independent=False,
-                 keep_images=0, noise=False, outliers=0, spread=0.1):
+                 keep_images=0, noise=False, outliers=0, spread=0.1, strip=False, roll=1.0):
         synth, shard = pkg.synth, pkg.shard
         self.pkg, self.torch = pkg, torch
         cam = {"480p": synth.TUM1, "720p": synth.HD720, "1080p": synth.HD1080}[res]
@@ -127,13 +132,19 @@ class Workload:
         self.independent = independent
         if independent:  # configs[4]: every GPU has its own sequence (seeds 0x5EED0050..57), no exchange
             self.n_total = kfs
-            self.scene = synth.Scene(cam, 0x5EED0050 + rank, disparity_px=disparity, noise_images=noise)
+            self.scene = synth.Scene(cam, 0x5EED0050 + rank, disparity_px=disparity, noise_images=noise, strip=strip,
+                                     roll_deg=roll)
             self.pl = shard.plan(kfs, 1, 0, N, self.scene.neighbours)
         else:
             self.n_total = kfs * world
-            self.scene = synth.Scene(cam, SEEDS[res], disparity_px=disparity, noise_images=noise)
+            self.scene = synth.Scene(cam, SEEDS[res], disparity_px=disparity, noise_images=noise, strip=strip, roll_deg=roll)
             self.pl = shard.plan(self.n_total, world, rank, N, self.scene.neighbours)
         pl = self.pl
+        self.strip, self.roll = strip, roll
+        self.rots = None
+        if roll != 1.0:  # the pairs' median in-plane rotations (PM.cc:170-179), per own keyframe and neighbour
+            self.rots = [[self.scene.rot_deg(k, j) for j in pl["nbrs"][i]] for i, k in enumerate(pl["own"])]
+            self.pl = pl = dict(pl, rot_of=dict(zip(pl["own_slots"], self.rots)))
         self.outliers = outliers
         n_slots = pl["n_slots"] * (2 if outliers else 1)
         self.spread = spread
@@ -170,7 +181,7 @@ class Workload:
 
     def step(self, exchange, transport, group=None):
         if self.outliers:  # K1 only: the wrong-pose copies are neighbours, never reference keyframes (no maps for K4)
-            self.eng.search_fuse(self.pl["own_slots"], self.pl["nbr_slots"], self.min_d, self.max_d)
+            self.eng.search_fuse(self.pl["own_slots"], self.pl["nbr_slots"], self.min_d, self.max_d, rot=self.rots)
             return
         self.pkg.shard.pipeline_step(self.eng, self.pool, self.pl, self.min_d, self.max_d, exchange, group, transport)
 
@@ -178,7 +189,7 @@ class Workload:
         eng, pl = self.eng, self.pl
         eng.enable_stats(True)
         eng.get_stats(reset=True)
-        eng.search_fuse(pl["own_slots"], pl["nbr_slots"], self.min_d, self.max_d)
+        eng.search_fuse(pl["own_slots"], pl["nbr_slots"], self.min_d, self.max_d, rot=self.rots)
         st = eng.get_stats()
         eng.enable_stats(False)
         return st
@@ -314,12 +325,13 @@ def scan_record(stats, k1_avg_ms):
 
 
 def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, barrier, noise=False, outliers=0, tag=None,
-              spread=0.1):
+              spread=0.1, strip=False, roll=1.0):
     """one more single-GPU workload, measured the same way as the headline one (cold and steady state)"""
-    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank, noise=noise, outliers=outliers, spread=spread)
+    wl = Workload(pkg, torch, res, kfs, N, disparity, 1, 0, local_rank, noise=noise, outliers=outliers, spread=spread,
+                  strip=strip, roll=roll)
     stats = wl.scan_stats()
     dt, timing, dt_c, timing_c, _ = measure(wl, steps, warmup, barrier, "halo", "torch")
-    plain = not (noise or outliers) and spread == 0.1
+    plain = not (noise or outliers or strip) and spread == 0.1 and roll == 1.0
     rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps,
                                                                noise=noise, outliers=outliers, spread=spread))
     rf_c, _ = roofline(wl, timing_c, steps, None)
@@ -333,6 +345,7 @@ def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, bar
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
         "ms_per_step_cold": round(dt_c / steps * 1e3, 4),
         "keyframes_total": wl.n_total, "neighbours": N, "disparity_px": disparity, "prior_spread": spread,
+        "scene": "strip" if strip else "plane", "roll_deg": roll,
         "stage_ms_per_step": {s: round(v[0] / steps, 4) for s, v in timing.items()},
         "roofline": rf,
         "mean_candidates_per_search": round(stats["candidates"] / max(stats["searches"], 1), 3),
@@ -395,7 +408,7 @@ def main():
 
     wl = Workload(pkg, torch, args.res, args.kfs, args.nbrs, args.disparity, world, rank, local_rank,
                   independent=args.independent, noise=args.noise, outliers=(args.outliers if world == 1 else 0),
-                  spread=args.prior_spread,
+                  spread=args.prior_spread, strip=(args.scene == "strip"), roll=args.roll,
                   keep_images=max(args.cpu_kfs + 2 * args.nbrs, min(args.kfs, 64)) if (rank == 0 and world == 1) else 0)
     eng, pl, W, H, N, P = wl.eng, wl.pl, wl.W, wl.H, wl.N, wl.P
     n_total = wl.n_total * (world if args.independent else 1)
@@ -493,6 +506,17 @@ def main():
         }
         eng.host_free(block)
 
+    streaming = None
+    if rank == 0 and world == 1 and wl.images and not args.outliers:
+        import gc
+        gc.collect()
+        gc.disable()  # (a full collection of this interpreter's heap costs ~40 ms: profiles/r05_upload_spikes.txt)
+        try:
+            streaming = {"pageable": streaming_rate(pkg, torch, wl), "pinned": streaming_rate(pkg, torch, wl, pinned=True)}
+        except Exception as e:  # noqa: BLE001 -- reported in the line, the headline must survive
+            streaming = {"error": repr(e)}
+        gc.enable()
+
     stats = None if args.no_stats else wl.scan_stats()  # untimed counting variant of K1
 
     def reduce_max(dt):
@@ -561,6 +585,9 @@ def main():
             "workload": workload_name(W, H, args.kfs, N, args.res, args.independent) +
                         (", i.i.d. uniform u8 noise images" if args.noise else "") +
                         (", depth prior s = %g mu" % args.prior_spread if args.prior_spread != 0.1 else "") +
+                        (", foreground strip with occluding edges" if args.scene == "strip" else "") +
+                        (", keyframes rolled by up to +-%g degrees (pairs carry their median rotation)" % args.roll
+                         if args.roll != 1.0 else "") +
                         (", %d wrong-pose neighbours per keyframe, K1 ONLY stepped (profiling form; `value` is not the "
                          "path's throughput)" % args.outliers if args.outliers else ""),
             "stages": "SemiDenseRecon(K1-K3)+%s+InterKFCheck(K4)+PointSet(K5, back-projected inside K4's kernel)" % xdesc,
@@ -622,12 +649,20 @@ def main():
         out["host_upload_ms_per_keyframe"] = round(upload_ms["batch_pageable"], 4)
         out["host_upload"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in upload_ms.items()}
         out["host_upload"]["unit"] = "ms per keyframe, wall clock incl. the device pre-pass (best of 3)"
+        if streaming and streaming.get("pageable"):
+            # sustained rate with the NEXT block's upload overlapping this block's step (double-buffered slots), everything
+            # included; value_pcie_inclusive below is the same work in series
+            out["value_streaming"] = round(streaming["pageable"], 2)
+            out["value_streaming_pinned"] = round(streaming["pinned"], 2) if streaming.get("pinned") else None
+        elif streaming:
+            out["value_streaming_error"] = streaming.get("error")
         out["value_pcie_inclusive"] = incl(upload_ms["batch_pageable"])
         out["value_pcie_inclusive_pinned"] = incl(upload_ms["batch_pinned"])
         out["value_pcie_inclusive_per_keyframe_calls"] = incl(upload_ms["per_keyframe_calls"])
 
     # ---- the other single-GPU BASELINE workloads, each measured like the headline one ----------------------
-    if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs, args.prior_spread) == ("480p", 64, 20, 0.1):
+    if world == 1 and not args.no_extra and (args.res, args.kfs, args.nbrs, args.prior_spread, args.scene, args.roll) == (
+            "480p", 64, 20, 0.1, "plane", 1.0):
         wl.close()
         extra = []
         xs = max(5, args.steps // 2)
@@ -642,11 +677,15 @@ def main():
                    dict(res="480p", kfs=64, N=20, disparity=args.disparity, spread=0.3,
                         tag="configs[1] with a wide depth prior (s = 0.3 mu, PM.cc:381-382)"),
                    dict(res="480p", kfs=64, N=20, disparity=10.0, spread=0.3,
-                        tag="configs[1] with a long baseline (10 px) AND a wide depth prior (s = 0.3 mu)")):
+                        tag="configs[1] with a long baseline (10 px) AND a wide depth prior (s = 0.3 mu)"),
+                   dict(res="480p", kfs=64, N=20, disparity=args.disparity, spread=0.3, strip=True, roll=5.0,
+                        tag="configs[1] on the two-plane scene (foreground strip, occluding edges), keyframes rolled by up to "
+                            "+-5 degrees with the matching median rotations, depth prior s = 0.3 mu")):
             try:
                 extra.append(run_extra(pkg, torch, kw["res"], kw["kfs"], kw["N"], kw["disparity"], xs, 2, local_rank,
                                        barrier, noise=kw.get("noise", False), outliers=kw.get("outliers", 0),
-                                       tag=kw.get("tag"), spread=kw.get("spread", 0.1)))
+                                       tag=kw.get("tag"), spread=kw.get("spread", 0.1), strip=kw.get("strip", False),
+                                       roll=kw.get("roll", 1.0)))
             except Exception as e:  # the headline line must survive a failing extra
                 extra.append({"workload": kw.get("tag") or "%s x %d KF x N=%d" % (kw["res"], kw["kfs"], kw["N"]),
                               "error": repr(e)})
@@ -656,6 +695,71 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
+    """Sustained ingest + compute (frames arrive continuously in the fork: src/Tracking.cc:266-271 -> Modeler.cc:1496-1514):
+    the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch into the OTHER half of a
+    double-sized slot pool, its staging and H2D copies running while the previous block's step executes -- then that block is
+    stepped (K1-K5).  Returns Mpix*KF/s over `iters` blocks, wall clock, everything included; the maps of the last two blocks
+    are compared with a serial upload-then-step of the same images (bit-equal, or the figure is not reported)."""
+    import numpy as np
+    pl = wl.pl
+    ks = [k for k in pl["own"] if k in wl.images]
+    if len(ks) != len(pl["own"]):
+        return None
+    n_slots = pl["n_slots"]
+    eng = pkg.Engine(wl.W, wl.H, 2 * n_slots, max_neighbours=wl.N, batch_capacity=min(wl.kfs, 64), with_pointset=True)
+    eng.set_ingest_overlap(True)
+    ims = [wl.images[k] for k in ks]
+    block = None
+    if pinned:
+        block = eng.host_alloc((len(ks), wl.H, wl.W))
+        for i, im in enumerate(ims):
+            block[i][...] = im
+        ims = [block[i] for i in range(len(ks))]
+    poses = [wl.scene.Tcw(k) for k in ks]
+    shift = lambda lst, off: [s_ + off for s_ in lst]
+    pls = []
+    for half in (0, 1):
+        off = half * n_slots
+        q = dict(pl, own_slots=shift(pl["own_slots"], off), nbr_slots=[shift(r, off) for r in pl["nbr_slots"]])
+        if "rot_of" in pl:
+            q["rot_of"] = {s_ + off: v for s_, v in pl["rot_of"].items()}
+        pls.append(q)
+    slots = [[pl["slot"][k] + half * n_slots for k in ks] for half in (0, 1)]
+
+    def step(half):
+        pkg.shard.pipeline_step(eng, None, pls[half], wl.min_d, wl.max_d, "none", None, "torch")
+
+    # serial reference: upload, step, read back
+    eng.upload_images_batch(slots[0], ims, wl.K, poses)
+    step(0)
+    want = [eng.download_checked(slots[0][i]) for i in (0, len(ks) // 2, len(ks) - 1)]
+    # streaming: block i is stepped while block i+1 is uploaded into the other half
+    for _ in range(2):  # warm-up round trips over both halves
+        eng.upload_images_batch(slots[1], ims, wl.K, poses)
+        step(1)
+        eng.upload_images_batch(slots[0], ims, wl.K, poses)
+        step(0)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.upload_images_batch(slots[0], ims, wl.K, poses)
+    for i in range(iters):
+        step(i & 1)                                                       # asynchronous: returns when the launches are queued
+        eng.upload_images_batch(slots[(i + 1) & 1], ims, wl.K, poses)     # the next block, while this one computes
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    ok = True
+    last = (iters - 1) & 1
+    for j, i in enumerate((0, len(ks) // 2, len(ks) - 1)):
+        ok = ok and np.array_equal(eng.download_checked(slots[last][i]).view(np.uint32), want[j].view(np.uint32))
+    if block is not None:
+        eng.host_free(block)
+    eng.close()
+    if not ok:
+        raise RuntimeError("streaming: the overlapped order's maps differ from the serial order's")
+    return wl.P * len(ks) * iters / dt / 1e6
 
 
 def cpu_baseline(args, wl):

@@ -68,6 +68,7 @@ typedef struct {
     long long mask_waves; /* (wave, neighbour) scans that took the gradient-mask scan instead of the batched one */
     long long mask_steps; /* mask words those scans examined (lane steps) */
     long long mask_row_mismatch; /* self-check of the mask scan's row runs: must stay 0 */
+    long long open_pixels; /* fusing pixels neither shortcut of InverseDepthHypothesisFusion settled: all-pairs count, PM.cc:598-626 */
 } sdm_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -304,6 +305,15 @@ int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
  * wave and neighbour, from the wave's range lengths and line slopes; 1: always the batched scan; 2: always the scan over the
  * neighbour's gradient-gate bit plane.  Results are the same bit for bit in every mode (tests/test_gpu_longscan.py). */
 int sdm_set_scan_mode(sdm_ctx *ctx, int mode);
+/* Overlapped ingest (default off).  On: the device work of a batch upload of two or more chunks (sdm_upload_images_batch /
+ * _rgb_batch: H2D copies, pre-pass kernels, list-length read-back) runs on the context's upload stream, ordered behind the
+ * last compute call (sdm_recon, sdm_inter_check*, sdm_pointset, ...) that used any of the slots being overwritten -- not
+ * behind everything queued on the compute stream -- and the compute stream waits for the upload.  A block of keyframes
+ * arriving into slots that nothing in flight uses (double-buffered slot sets: frames arrive continuously in the fork,
+ * src/Tracking.cc:266-271) then overlaps the step that is executing, and the calls that queue the next step do not wait for
+ * the previous one to drain.  Results are the ones of the serial order (tests/test_gpu_ingest.py).  Uploads of a single chunk,
+ * of device-resident images, and uploads issued while an exchange is in flight keep the serial order.  Host-blocking. */
+int sdm_set_ingest_overlap(sdm_ctx *ctx, int on);
 /* per-stage device time measured with HIP events recorded on the context's stream around each
  * stage's kernel launches (K1 = one k_search_fuse launch per sdm_recon/sdm_search_fuse call) */
 #define SDM_STAGE_SEARCH_FUSE 0 /* K1   PM.cc:197-231 */

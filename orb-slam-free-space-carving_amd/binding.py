@@ -30,7 +30,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("searches", C.c_longlong), ("candidates", C.c_longlong), ("gate_pass", C.c_longlong),
                 ("hypotheses", C.c_longlong), ("fused", C.c_longlong), ("mask_waves", C.c_longlong),
-                ("mask_steps", C.c_longlong), ("mask_row_mismatch", C.c_longlong)]
+                ("mask_steps", C.c_longlong), ("mask_row_mismatch", C.c_longlong), ("open_pixels", C.c_longlong)]
 
 
 def lib_path():
@@ -113,6 +113,7 @@ SYMBOLS = [
     ("sdm_get_stats", C.c_int, [_ctx, C.POINTER(Stats), C.c_int]),
     ("sdm_set_scan_mode", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_params", C.c_int, [_ctx, C.POINTER(Params)]),
+    ("sdm_set_ingest_overlap", C.c_int, [_ctx, C.c_int]),
     ("sdm_selftest", C.c_int, [_ctx, C.c_int, C.POINTER(C.c_ulonglong)]),
     ("sdm_enable_timing", C.c_int, [_ctx, C.c_int]),
     ("sdm_get_timing", C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
@@ -562,6 +563,10 @@ class Engine:
         return F, R, t
 
     # -- instrumentation ---------------------------------------------------------------------------------
+    def set_ingest_overlap(self, on=True):
+        """batch uploads overlap the compute calls that do not use their slots (sdm_c.h sdm_set_ingest_overlap)"""
+        self._check(self.lib.sdm_set_ingest_overlap(self.ctx, 1 if on else 0))
+
     def set_scan_mode(self, mode):
         """0 = per wave (default), 1 = batched scan, 2 = gradient-mask scan (diagnostic; results are identical)"""
         self._check(self.lib.sdm_set_scan_mode(self.ctx, int(mode)))

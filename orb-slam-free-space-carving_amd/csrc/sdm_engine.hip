@@ -126,6 +126,19 @@ struct sdm_ctx {
     int mrow = 0;                              // 32-bit words per image row: 2 * (tiles_x + 1) (the last two stay zero: the scan
                                                // reads the word after the one a column lies in)
     int scan_mode = 0;                         // DevParams::scan_mode (SDM_SCAN_MODE, read once in sdm_create)
+    // ---- overlapped ingest (sdm_set_ingest_overlap): a batch upload's device work -- copies, pre-pass, list lengths -- runs
+    // on the upload stream, ordered behind the last compute call that used any of the slots it overwrites (one event per
+    // compute call, a ring of them) instead of behind everything queued on the compute stream; the compute stream waits for
+    // the upload.  A block arriving into slots nothing in flight uses overlaps the step that is executing.
+    bool ingest_overlap = false;
+    static constexpr int USE_RING = 64;
+    hipEvent_t use_ev[USE_RING] = {};
+    unsigned long long use_next = 1;              // id of the next compute call (0 = never used)
+    std::vector<unsigned long long> slot_use;     // [max_keyframes] id of the last compute call that touched the slot
+    hipEvent_t ev_ingest = nullptr, ev_counts = nullptr;
+    bool counts_on_upload_stream = false;         // the pending list-length read-back was queued on the upload stream
+    unsigned long long misc_last = 0;             // id of the last compute-stream operation that wrote slots without naming
+                                                  // them through a table set (uploads on the compute stream, list rebuilds, ...)
     bool validated = false;                    // validate_params: the last non-default parameter set checked on the device ...
     sdm_params validated_prm{};
     int validated_closed = 0, validated_approx = 0;  // ... and what held for it
@@ -267,12 +280,12 @@ int validate_params(sdm_ctx* c)
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
     unsigned long long out[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream));
     hipLaunchKernelGGL(k_selftest_gates, dim3(4096), dim3(BLOCK), 0, c->stream, c->dprm, c->d_stats + 4, c->d_stats + 5);
     hipLaunchKernelGGL(k_selftest_cost, dim3(256), dim3(BLOCK), 0, c->stream, c->dprm, 256, c->d_stats + 6, c->d_stats + 7);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->d_stats + 4, sizeof(out), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const double th = c->prm.theta_var;
     c->validated_closed = (out[0] == 0 && out[1] > 0) ? 1 : 0;
@@ -297,61 +310,69 @@ int ingest_acquire(sdm_ctx* c, int b, hipStream_t copy_stream)
         B.copied_pending = false;
     }
     if (B.consumed_pending) {
-        if (copy_stream != c->stream) HIP_TRY(hipStreamWaitEvent(copy_stream, B.consumed, 0));  // (same stream: ordered anyway)
+        HIP_TRY(hipStreamWaitEvent(copy_stream, B.consumed, 0));  // (the kernels may have run on either stream)
         B.consumed_pending = false;
     }
     return SDM_OK;
 }
 // the chunk's item table goes up behind whatever image copies were queued on the upload stream; the compute stream waits
 // for all of it
-int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream)
+int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream, hipStream_t ks = nullptr)
 {
+    if (!ks) ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, copy_stream));
     HIP_TRY(hipEventRecord(B.copied, copy_stream));
     B.copied_pending = true;
-    if (copy_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, B.copied, 0));
+    if (copy_stream != ks) HIP_TRY(hipStreamWaitEvent(ks, B.copied, 0));
     return SDM_OK;
 }
 // list lengths of the chunk's slots -> pinned host mirror (one copy when the slots are consecutive)
-int ingest_counts(sdm_ctx* c, int m, const int* slots)
+int ingest_counts(sdm_ctx* c, int m, const int* slots, hipStream_t ks = nullptr)
 {
+    if (!ks) ks = c->stream;
     bool run = true;
     for (int i = 1; i < m; i++) run = run && slots[i] == slots[0] + i;
     if (run) {
         HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[0]], c->d_act_count + slots[0], sizeof(int) * (size_t)m,
-                               hipMemcpyDeviceToHost, c->stream));
+                               hipMemcpyDeviceToHost, ks));
     } else {
         for (int i = 0; i < m; i++)
-            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost,
-                                   c->stream));
+            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost, ks));
     }
     c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
+    if (ks != c->stream) {
+        HIP_TRY(hipEventRecord(c->ev_counts, ks));
+        c->counts_on_upload_stream = true;
+    }
     return SDM_OK;
 }
 // the three launches of a chunk on the compute stream (+ k_ingest_batch for colour / distorted frames)
-int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q)
+int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q, hipStream_t ks = nullptr)
 {
+    if (!ks) ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     const int tiles_x = c->geom.tiles_x, ntiles = c->geom.ntiles;
-    if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, *q);
+    if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, *q);
     if (from_images)
-        hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P,
+        hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, tiles_x, c->P,
                            c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask,
                            c->mrow);
     else
-        hipLaunchKernelGGL(k_gate_batch, dim3(ntiles, m), dim3(BLOCK), 0, c->stream, B.d_items, c->W, c->H, tiles_x, c->P, c->rec,
+        hipLaunchKernelGGL(k_gate_batch, dim3(ntiles, m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, tiles_x, c->P, c->rec,
                            c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask, c->mrow);
-    hipLaunchKernelGGL(k_prepass_finish, dim3(m), dim3(FIN_BLOCK), 0, c->stream, B.d_items, c->W, c->H, ntiles, c->nseg, c->d_part,
+    hipLaunchKernelGGL(k_prepass_finish, dim3(m), dim3(FIN_BLOCK), 0, ks, B.d_items, c->W, c->H, ntiles, c->nseg, c->d_part,
                        c->d_seg_mask, c->d_seg_off, c->d_meta, c->d_act_count, c->d_theta_bad, c->d_act_hash,
                        from_images ? 1 : 0);
-    hipLaunchKernelGGL(k_list_write, dim3((c->nseg + BLOCK / 64 - 1) / (BLOCK / 64), m), dim3(BLOCK), 0, c->stream, B.d_items,
+    hipLaunchKernelGGL(k_list_write, dim3((c->nseg + BLOCK / 64 - 1) / (BLOCK / 64), m), dim3(BLOCK), 0, ks, B.d_items,
                        tiles_x, c->nseg, c->P, c->d_seg_mask, c->d_seg_off, c->d_act);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(B.consumed, c->stream));
+    HIP_TRY(hipEventRecord(B.consumed, ks));
     B.consumed_pending = true;
     return SDM_OK;
 }
+
+int note_misc(sdm_ctx* c);
 
 // (re)build the active-pixel lists of `n` slots from their records for the current lambdaG (sdm_set_params changed it, or
 // the records came from the caller's own planes); the counts come back asynchronously
@@ -383,7 +404,7 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
         c->act_lambdaG[slot] = c->dprm.lambdaG;
     }
     c->epoch++;
-    return SDM_OK;
+    return note_misc(c);
 }
 int build_active(sdm_ctx* c, int slot) { return rebuild_lists(c, 1, &slot); }
 
@@ -391,7 +412,12 @@ int build_active(sdm_ctx* c, int slot) { return rebuild_lists(c, 1, &slot); }
 int sync_counts(sdm_ctx* c)
 {
     if (c->counts_pending) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->counts_on_upload_stream) {  // (overlapped ingest: the compute stream may be busy with an earlier step)
+            HIP_TRY(hipEventSynchronize(c->ev_counts));
+            c->counts_on_upload_stream = false;
+        } else {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         c->counts_pending = false;
     }
     return SDM_OK;
@@ -621,9 +647,26 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     return SDM_OK;
 }
 
+// an operation on the compute stream that writes slot data outside the table sets (see sdm_ctx::misc_last)
+int note_misc(sdm_ctx* c)
+{
+    if (!c->ingest_overlap) return SDM_OK;
+    const unsigned long long id = c->use_next++;
+    HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
+    c->misc_last = id;
+    return SDM_OK;
+}
+
+// end of a compute call (the staging block itself is released by the event recorded in stage_tables): with overlapped
+// ingest on, remember which slots the call used and mark its end on the compute stream
 int tables_staged(sdm_ctx* c)
 {
-    (void)c;  // the staging block is released by the event recorded in stage_tables
+    if (!c->ingest_overlap) return SDM_OK;
+    const sdm_ctx::TableKey& k = c->sets[c->cur_set].key;
+    const unsigned long long id = c->use_next++;
+    HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
+    for (int s_ : k.refs) c->slot_use[(size_t)s_] = id;
+    for (int s_ : k.nbrs) c->slot_use[(size_t)s_] = id;
     return SDM_OK;
 }
 
@@ -766,6 +809,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->recon_lambdaG.assign(K, std::nanf(""));
     c->chk_sparse.assign(K, 1);  // planes start zeroed
     c->xyz_sparse.assign(K, 1);
+    c->slot_use.assign(K, 0);
 
     int rc = SDM_OK;
     auto bail = [&](int code) {
@@ -829,8 +873,20 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         c->nseg = c->H * c->geom.tiles_x;
         c->ing_cap = (int)std::max<long long>(1, std::min<long long>(std::min(64, K), ((long long)32 << 20) / c->P));
         c->src_bytes = (size_t)std::max<long long>((long long)c->ing_cap * c->P, 4 * c->P);
-        if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess)
-            return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
+        {
+            // the upload stream at the highest priority the device offers: its copies and the short pre-pass kernels run
+            // NEXT TO a step that fills the GPU (at equal priority they waited behind K1's 60 000 workgroups: measured)
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+            if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p) != hipSuccess)
+                return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
+        }
+        if (hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_counts, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+        for (int i = 0; i < sdm_ctx::USE_RING; i++)
+            if (hipEventCreateWithFlags(&c->use_ev[i], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(SDM_EHIP, "hipEventCreate failed"));
         for (int b = 0; b < 2; b++) {
             sdm_ctx::IngestBuf& B = c->ing[b];
             if ((rc = dev_alloc(&B.d_img, (size_t)c->ing_cap * c->P)) || (rc = host_alloc(&B.h_ring, (size_t)c->ing_cap * c->P)) ||
@@ -853,7 +909,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     if ((rc = dev_alloc(&c->d_grad, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_theta, (size_t)c->P))) return bail(rc);
     if ((rc = dev_alloc(&c->d_small, 16))) return bail(rc);
-    if ((rc = dev_alloc(&c->d_stats, 8))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_stats, STATS_WORDS))) return bail(rc);
     const size_t np = (size_t)K * cfg->max_neighbours;
     c->tab_bytes = 4 * ((size_t)K * 3 + np * 2 + 2) + sizeof(long long) * 3 * (size_t)K;
     for (int si = 0; si < sdm_ctx::TABLE_SETS; si++) {
@@ -877,7 +933,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         hipMemsetAsync(c->d_theta_bad, 0, sizeof(int) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_act_hash, 0, sizeof(unsigned long long) * K, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_gmask, 0, sizeof(unsigned) * (size_t)K * c->H * MASK_PLANES * c->mrow, c->stream) != hipSuccess ||
-        hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream) != hipSuccess ||
         (c->xyz && hipMemsetAsync(c->xyz, 0, sizeof(float) * 3 * c->P * K, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
         return bail(fail(SDM_EHIP, "initial memset failed"));
@@ -929,6 +985,10 @@ void sdm_destroy(sdm_ctx* c)
         if (B.consumed) (void)hipEventDestroy(B.consumed);
     }
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->ev_ingest) (void)hipEventDestroy(c->ev_ingest);
+    if (c->ev_counts) (void)hipEventDestroy(c->ev_counts);
+    for (int i = 0; i < sdm_ctx::USE_RING; i++)
+        if (c->use_ev[i]) (void)hipEventDestroy(c->use_ev[i]);
     (void)hipFree(c->d_part);
     (void)hipFree(c->d_seg_mask);
     (void)hipFree(c->d_seg_off);
@@ -1013,7 +1073,7 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     m.I_stddev = I_stddev;
     m.uploaded = 1;
     if ((rc = push_meta(c, slot, false))) return rc;
-    if ((rc = build_active(c, slot))) return rc;
+    if ((rc = build_active(c, slot))) return rc;  // (ends with note_misc)
     return sync_counts(c);  // the caller's (pageable) planes are released on return
 }
 
@@ -1151,6 +1211,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
                   const float* K, const float* Tcw)
 {
     static const bool dbg = getenv("SDM_DEBUG_INGEST_TIMING") != nullptr;
+    static const double dbg_ms = dbg && atof(getenv("SDM_DEBUG_INGEST_TIMING")) > 0 ? atof(getenv("SDM_DEBUG_INGEST_TIMING")) : 2.0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_entry = dbg ? now() : 0.0;
     int rc = check_batch_slots(c, n, slots);
@@ -1181,6 +1242,23 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
     // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
     const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
+    // overlapped ingest (sdm_set_ingest_overlap): the kernels and the list-length read-back go to the upload stream as well,
+    // which first waits for the last compute call that used any of the target slots -- not for everything queued on the
+    // compute stream.  Not while an exchange is in flight (its transfers are ordered against the compute stream only) and not
+    // for images that live in device memory (whatever produced them is ordered against the compute stream only).
+    const bool overlap = c->ingest_overlap && n_chunks > 1 && !on_device && !c->xchg_pending && !c->ag_open;
+    const hipStream_t ks = overlap ? c->up_stream : c->stream;
+    if (overlap) {
+        unsigned long long id = c->misc_last;
+        for (int i = 0; i < n; i++) id = std::max(id, c->slot_use[(size_t)slots[i]]);
+        if (id != 0) {
+            if (c->use_next - id >= (unsigned long long)sdm_ctx::USE_RING) {  // its event was recycled: wait for "now" instead
+                id = c->use_next++;
+                HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
+            }
+            HIP_TRY(hipStreamWaitEvent(c->up_stream, c->use_ev[id % sdm_ctx::USE_RING], 0));
+        }
+    }
     double tdbg[6] = {0, 0, 0, 0, 0, 0};
     const double t_loop = dbg ? now() : 0.0;
     // An error in the middle of a batch: copies that read the caller's pinned images may still be in flight -- they are awaited
@@ -1239,7 +1317,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
             }
         }
         if (dbg) tdbg[2] = now();
-        if ((rc = ingest_publish(c, b, m, cs))) return bail(rc);
+        if ((rc = ingest_publish(c, b, m, cs, ks))) return bail(rc);
         if (dbg) tdbg[3] = now();
         for (int i = 0; i < m; i++) {
             const int slot = slots[i0 + i];
@@ -1247,12 +1325,12 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
             c->h_meta[slot] = B.h_items[i].meta;  // (I_stddev lives on the device only)
             c->act_lambdaG[slot] = c->dprm.lambdaG;
         }
-        if ((rc = ingest_launch(c, b, m, true, q))) return bail(rc);
+        if ((rc = ingest_launch(c, b, m, true, q, ks))) return bail(rc);
         if (dbg) tdbg[4] = now();
-        if ((rc = ingest_counts(c, m, slots + i0))) return bail(rc);
+        if ((rc = ingest_counts(c, m, slots + i0, ks))) return bail(rc);
         if (dbg) {
             tdbg[5] = now();
-            if (tdbg[5] - tdbg[0] > 2.0)
+            if (tdbg[5] - tdbg[0] > dbg_ms)
                 fprintf(stderr, "[sdm ingest] slow chunk: acquire %.3f  images %.3f  publish %.3f  launch %.3f  counts %.3f ms\n",
                         tdbg[1] - tdbg[0], tdbg[2] - tdbg[1], tdbg[3] - tdbg[2], tdbg[4] - tdbg[3], tdbg[5] - tdbg[4]);
         }
@@ -1260,12 +1338,18 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     }
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
     // in place are awaited here (the pre-pass kernels are not)
+    if (overlap) {  // everything queued on the compute stream from here on sees the new keyframes
+        HIP_TRY(hipEventRecord(c->ev_ingest, c->up_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ingest, 0));
+    } else if ((rc = note_misc(c))) {
+        return rc;
+    }
     const double t_tail = dbg ? now() : 0.0;
     if (direct && last >= 0) {
         HIP_TRY(hipEventSynchronize(c->ing[last].copied));
         c->ing[last].copied_pending = false;
     }
-    if (dbg && now() - t_entry > 2.0)
+    if (dbg && now() - t_entry > dbg_ms)
         fprintf(stderr, "[sdm ingest] slow call (%d keyframes): set-up %.3f  chunks %.3f  final wait %.3f ms\n", n, t_loop - t_entry,
                 t_tail - t_loop, now() - t_tail);
     return SDM_OK;
@@ -1844,7 +1928,8 @@ int sdm_upload_depth(sdm_ctx* c, int slot, const float* rho, const float* sigma)
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->has_depth[slot] = 1;
     c->recon_lambdaG[slot] = std::nanf("");  // arbitrary map: support is no longer tied to the active list
-    return upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma);
+    if ((rc = upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma))) return rc;
+    return note_misc(c);
 }
 
 int sdm_download_depth(sdm_ctx* c, int slot, float* rho, float* sigma)
@@ -2061,7 +2146,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
 {
     if (!c || !out) return fail(SDM_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream));
     if (which == 0) {
         hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(BLOCK), 0, c->stream, c->dprm.theta_var, c->dprm.inv_theta,
                            c->d_stats + 5);
@@ -2095,7 +2180,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
         (void)hipFree(d_patch);
         (void)hipFree(d_pc);
         if (e != hipSuccess) return fail(SDM_EHIP, hipGetErrorString(e));
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream));
         return SDM_OK;
     } else if (which == 6) {
         hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(BLOCK), 0, c->stream, c->d_stats + 5, c->d_stats + 6);
@@ -2109,7 +2194,7 @@ int sdm_selftest(sdm_ctx* c, int which, unsigned long long out[2])
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->d_stats + 5, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * STATS_WORDS, c->stream));
     return SDM_OK;
 }
 
@@ -2138,6 +2223,20 @@ int sdm_get_timing(sdm_ctx* c, double ms_total[SDM_NUM_STAGES], long long launch
     return SDM_OK;
 }
 
+int sdm_set_ingest_overlap(sdm_ctx* c, int on)
+{
+    if (!c) return fail(SDM_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // a clean start: nothing in flight that the tracking has not seen
+    if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
+    c->counts_pending = false;
+    c->counts_on_upload_stream = false;
+    c->ingest_overlap = on != 0;
+    std::fill(c->slot_use.begin(), c->slot_use.end(), 0ull);
+    c->misc_last = 0;
+    return SDM_OK;
+}
+
 int sdm_set_scan_mode(sdm_ctx* c, int mode)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
@@ -2150,7 +2249,7 @@ int sdm_set_scan_mode(sdm_ctx* c, int mode)
 int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
 {
     if (!c || !out) return fail(SDM_EINVAL, "null argument");
-    unsigned long long v[8];
+    unsigned long long v[STATS_WORDS];
     HIP_TRY(hipMemcpyAsync(v, c->d_stats, sizeof(v), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->searches = (long long)v[0];
@@ -2161,6 +2260,7 @@ int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
     out->mask_waves = (long long)v[5];
     out->mask_steps = (long long)v[6];
     out->mask_row_mismatch = (long long)v[7];
+    out->open_pixels = (long long)v[8];
     if (reset) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(v), c->stream));
     return SDM_OK;
 }

@@ -289,6 +289,7 @@ __host__ __device__ inline size_t k1_lds_bytes(int n)
 // Pixels whose fusion neither bound settles are not finished by their workgroup: they are appended -- hypotheses and all --
 // to a per-launch list, and k_fuse_open runs the all-pairs count for 64 OPEN pixels per workgroup.  A clean workgroup
 // never pays the pair loop because one of its 64 pixels is open.
+constexpr int STATS_WORDS = 16;  // sdm_stats counters (the self-tests borrow words 4 .. 7)
 struct OpenList {
     unsigned* count;          // this launch's counters: [0] open pixels seen so far (decides the quota below), [1] the first
                               // list reservation that did not fit (else ~0u), [2] list entries reserved.  Reservations are
@@ -636,10 +637,11 @@ __global__ SDM_K1_LB void k_search_fuse(const float4* __restrict__ rec, long lon
         pool[(long long)rc.slot * plane + y * W + x] = result;
     }
     if (STATS) {
-        unsigned long long v[8] = {st.searches, st.candidates, st.gate_pass,
-                                   (w == 0 && on) ? (unsigned long long)nh : 0ull, n_fused, ms.waves, ms.steps, ms.row_mismatch};
+        unsigned long long v[9] = {st.searches, st.candidates, st.gate_pass,
+                                   (w == 0 && on) ? (unsigned long long)nh : 0ull, n_fused, ms.waves, ms.steps, ms.row_mismatch,
+                                   (w == 0 && open) ? 1ull : 0ull};
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 9; k++) {
             unsigned long long s = v[k];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
             if ((tid & 63) == 0 && s) atomicAdd(&stats[k], s);

@@ -411,6 +411,10 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
     boundary, interior = pl["boundary_slots"], pl["interior_slots"]
     early, late = pl["check_early_slots"], pl["check_late_slots"]
     native = transport == "native"
+    rot_of = pl.get("rot_of")  # optional {slot: [median in-plane rotation per neighbour, degrees]} (PM.cc:170-179)
+
+    def recon(slots, nb, mn, mx):
+        eng.recon(slots, nb, mn, mx, rot=None if rot_of is None else [rot_of[k] for k in slots])
 
     def check(slots):  # K4 with K5 riding along (PM.cc:300-306); snapshot form: the pool's maps stay as reconstructed
         if slots:
@@ -419,7 +423,7 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
     # In every sharded form the keyframes whose K4 reads no other rank's map are checked BEFORE the wait for the exchange
     # (the transfer has the interior keyframes' K1-K3 and their K4 to hide behind), the others after it.
     if world > 1 and exchange == "halo" and boundary:
-        eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+        recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
         compact = (not native) and getattr(eng, "compact_entries", 0) > 0
         if native:
             eng.exchange_halo_begin(*halo_lists(pl))
@@ -428,7 +432,7 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         else:
             works = exchange_halo_async(pool, pl, group)
         if interior:
-            eng.recon(interior, [nb_of[k] for k in interior], min_d, max_d)
+            recon(interior, [nb_of[k] for k in interior], min_d, max_d)
         check(early)
         if native:
             eng.exchange_wait()
@@ -444,15 +448,15 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         # all-gather of the maps that cross ranks: reconstruct the boundary keyframes, start the collective on the
         # engine's exchange stream, reconstruct the interior keyframes meanwhile
         if boundary:
-            eng.recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
+            recon(boundary, [nb_of[k] for k in boundary], min_d, max_d)
         else:
-            eng.recon(own[:1], nbrs[:1], min_d, max_d)  # nothing crosses ranks: the (padded) contribution still needs a map
+            recon(own[:1], nbrs[:1], min_d, max_d)  # nothing crosses ranks: the (padded) contribution still needs a map
         rest = interior if boundary else own[1:]
         if native:
             eng.allgather_begin(pl["contrib_count"])
             eng.allgather_piece(contrib_slots(pl))
             if rest:
-                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+                recon(rest, [nb_of[k] for k in rest], min_d, max_d)
             check(early)
             eng.allgather_finish(contrib_fetch_list(pl))
         elif getattr(eng, "compact_entries", 0) > 0:
@@ -460,12 +464,12 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
             allgather_boundary_compact(codec, pl, group)
             eng.staged_refused = getattr(eng, "staged_refused", 0) + codec.refused
             if rest:
-                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+                recon(rest, [nb_of[k] for k in rest], min_d, max_d)
             check(early)
         else:
             allgather_boundary(pool, pl, group)
             if rest:
-                eng.recon(rest, [nb_of[k] for k in rest], min_d, max_d)
+                recon(rest, [nb_of[k] for k in rest], min_d, max_d)
             check(early)
             eng.mark_depth_present([s for _, s in contrib_fetch_list(pl)])
         check(late)
@@ -473,7 +477,7 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         # the boundary all-gather WITHOUT splitting the reconstruction: K1-K3 over the whole block in one set of launches (no
         # second K1 launch with its tail), then the collective with only the local keyframes' K4 to hide behind.  Cheaper on
         # the compute side, a third of the window: the better schedule when the transfer is short (compact wire format).
-        eng.recon(own, nbrs, min_d, max_d)
+        recon(own, nbrs, min_d, max_d)
         if native:
             eng.allgather_begin(pl["contrib_count"])
             eng.allgather_piece(contrib_slots(pl))
@@ -494,14 +498,14 @@ def pipeline_step(eng, pool, pl, min_d, max_d, exchange="allgather", group=None,
         # the engine's exchange stream while the next one's K1-K3 run (sdm_allgather_begin / _piece / _finish)
         eng.allgather_begin(pl["count"])
         for off, cnt in sub_blocks(pl["count"], ag_pieces):
-            eng.recon(own[off:off + cnt], nbrs[off:off + cnt], min_d, max_d)
+            recon(own[off:off + cnt], nbrs[off:off + cnt], min_d, max_d)
             eng.allgather_piece(own[off:off + cnt])
         check(early)
         # position in the owner's block == keyframe - owner's first keyframe; owner * count + position == keyframe
         eng.allgather_finish(fetch_list(pl))
         check(late)
     else:
-        eng.recon(own, nbrs, min_d, max_d)
+        recon(own, nbrs, min_d, max_d)
         if world > 1:
             if native:
                 eng.allgather_depth(pl["first_slot"], pl["count"], fetch_list(pl))

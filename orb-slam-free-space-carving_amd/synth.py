@@ -50,16 +50,23 @@ class Scene:
 
     N_WAVES = 32
 
-    def __init__(self, cam, seed, disparity_px=2.6, z0=1.0, noise_images=False):
+    def __init__(self, cam, seed, disparity_px=2.6, z0=1.0, noise_images=False, strip=False, roll_deg=1.0):
         """disparity_px: disparity between adjacent keyframes at depth Z0 (App. D's b = 0.005*Z0
         at TUM1's fx is 2.6 px); it is the knob that sets the mean scan length of PM.cc:405.
         Texture frequencies are App. D's [2,40] cycles/unit at TUM1's fx, rescaled with fx so the
-        texture has the same period in PIXELS (13..260 px) at every resolution."""
+        texture has the same period in PIXELS (13..260 px) at every resolution.
+        strip: App. D's optional second plane -- a fronto-parallel foreground strip at 0.75 Z0 with its own texture, a quarter
+        of the view wide: a depth discontinuity with an occluding edge on either side (the background next to it is seen by
+        some keyframes and hidden from others as the camera moves along X).
+        roll_deg: keyframe k's in-plane roll is drawn from [-roll_deg, roll_deg] (1 degree in App. D); with larger values a
+        pair's images are rotated against each other and PM.cc:170-179's median rotation (rot_deg) is no longer ~0."""
         self.cam = dict(cam)
         self.seed = seed
         self.z0 = z0
         self.b = disparity_px * z0 / cam["fx"]
         self.noise_images = noise_images
+        self.strip = bool(strip)
+        self.roll_deg = float(roll_deg)
         fscale = cam["fx"] / TUM1["fx"]
         r = SplitMix64(seed)
         self.alpha = r.uniform(-0.1, 0.1)
@@ -70,6 +77,11 @@ class Scene:
         self.psi = [r.uniform(0.0, 2 * math.pi) for _ in range(self.N_WAVES)]
         self.wgt = [r.uniform(0.5, 1.0) for _ in range(self.N_WAVES)]
         self._rot_seed = r.next()
+        # the foreground strip (drawn AFTER everything the one-plane scene draws: the same seed gives the same background)
+        self.strip_z = 0.75 * z0
+        half_view = 0.5 * cam["W"] / cam["fx"] * z0
+        self.strip_x0 = -0.25 * half_view            # world X extent, about a quarter of the view at keyframe 0
+        self.strip_x1 = self.strip_x0 + 0.5 * half_view
         # amplitude: ~20 % of pixels should pass the lambdaG = 8 gate (Scharr/32 magnitude).  The
         # analytic gradient of the texture in pixels is |dT/dX| / f (one pixel = 1/fx world units
         # at Z0); pick A so that the 80th percentile of that magnitude is 8 gray levels per pixel.
@@ -92,7 +104,7 @@ class Scene:
         b = self.b
         C = np.array([k * b, 0.1 * b * math.sin(0.7 * k), 0.05 * b * math.cos(0.3 * k)])
         r = SplitMix64(self._rot_seed ^ (0xA5A5A5A5 + 0x9E3779B97F4A7C15 * (k + 1)))
-        roll = math.radians(r.uniform(-1.0, 1.0))
+        roll = math.radians(r.uniform(-1.0, 1.0) * self.roll_deg)
         pitch = math.radians(r.uniform(-0.3, 0.3))
         yaw = math.radians(r.uniform(-0.3, 0.3))
         cz, sz = math.cos(roll), math.sin(roll)
@@ -102,6 +114,18 @@ class Scene:
         Rx = np.array([[1.0, 0, 0], [0, cx_, -sx_], [0, sx_, cx_]])
         Ry = np.array([[cy_, 0, sy_], [0, 1.0, 0], [-sy_, 0, cy_]])
         return Ry @ Rx @ Rz, C
+
+    def roll(self, k):
+        """keyframe k's in-plane roll in degrees (the first draw of pose(k))"""
+        r = SplitMix64(self._rot_seed ^ (0xA5A5A5A5 + 0x9E3779B97F4A7C15 * (k + 1)))
+        return r.uniform(-1.0, 1.0) * self.roll_deg
+
+    def rot_deg(self, k_ref, k_nbr):
+        """What PM.cc:170-179 would measure for the pair: the median over shared ORB features of (angle in the neighbour -
+        angle in the reference).  A camera rolled by +r about its optical axis sees the scene rotated by -r, so image
+        directions in the neighbour are those of the reference plus roll(ref) - roll(nbr) (pitch / yaw of 0.3 degrees do
+        not matter at this precision).  float32, as GetRotInPlane returns it."""
+        return float(np.float32(self.roll(k_ref) - self.roll(k_nbr)))
 
     def Tcw(self, k):
         Rwc, C = self.pose(k)
@@ -127,6 +151,13 @@ class Scene:
         dy = Rwc[1, 0] * xn + Rwc[1, 1] * yn + Rwc[1, 2]
         dz = Rwc[2, 0] * xn + Rwc[2, 1] * yn + Rwc[2, 2]
         s = (self.z0 + self.alpha * C[0] + self.beta * C[1] - C[2]) / (dz - self.alpha * dx - self.beta * dy)
+        fg = None
+        if self.strip:  # ray / foreground-plane intersection; the strip wins where the hit lies inside its X extent
+            s2 = (self.strip_z - C[2]) / dz
+            X2 = C[0] + s2 * dx
+            fg = (X2 >= self.strip_x0) & (X2 <= self.strip_x1) & (s2 > 0) & (s2 < s)
+            s = torch.where(fg, s2, s)
+        self.last_fg = fg  # (H, W) bool of the last rendered keyframe's foreground pixels, or None
         gt_rho = (1.0 / s).to(torch.float32)
         if self.noise_images:
             g = torch.Generator(device="cpu").manual_seed((int(self.seed) * 1000003 + k) & 0x7FFFFFFF)
@@ -138,6 +169,13 @@ class Scene:
         for i in range(self.N_WAVES):
             w = 2 * math.pi * self.freq[i]
             T += self.wgt[i] * torch.sin(w * (X * math.cos(self.phi[i]) + Y * math.sin(self.phi[i])) + self.psi[i])
+        if fg is not None:  # the strip's own texture: the same spectrum, directions and phases permuted
+            T2 = torch.zeros_like(X)
+            for i in range(self.N_WAVES):
+                j = (7 * i + 3) % self.N_WAVES
+                w = 2 * math.pi * self.freq[i] * (self.z0 / self.strip_z)
+                T2 += self.wgt[j] * torch.sin(w * (X * math.cos(self.phi[j] + 1.0) + Y * math.sin(self.phi[j] + 1.0)) + self.psi[i] + 2.0)
+            T = torch.where(fg, T2, T)
         im = torch.clamp(torch.floor(127.5 + self.amp * T + 0.5), 0, 255).to(torch.uint8)
         return im, gt_rho
 

@@ -23,23 +23,27 @@ class Sequence:
     """n_kf synthetic keyframes (images + oracle-derived gradient inputs + poses)."""
 
     def __init__(self, pkg, oracle, W, H, n_kf, seed, disparity_px=2.6, base="TUM1", noise=False,
-                 images=None):
+                 images=None, strip=False, roll_deg=1.0):
         synth = pkg.synth
         cam0 = getattr(synth, base)
         cam = cam0 if (W, H) == (cam0["W"], cam0["H"]) else synth.scaled_intrinsics(cam0, W, H)
-        self.scene = synth.Scene(cam, seed, disparity_px=disparity_px, noise_images=noise)
+        self.scene = synth.Scene(cam, seed, disparity_px=disparity_px, noise_images=noise, strip=strip, roll_deg=roll_deg)
+        self.with_rot = roll_deg != 1.0  # pairs carry PM.cc:170-179's median in-plane rotation (else 0, as App. D says)
         self.W, self.H, self.n_kf = W, H, n_kf
         self.K = self.scene.K()
         self.Tcw = [self.scene.Tcw(k) for k in range(n_kf)]
-        self.im, self.gt = [], []
+        self.im, self.gt, self.fg = [], [], []
         for k in range(n_kf):
             if images is not None:
                 self.im.append(np.ascontiguousarray(images[k], dtype=np.uint8))
                 self.gt.append(None)
+                self.fg.append(None)
             else:
                 im, gt = self.scene.render(k)
                 self.im.append(im.numpy())
                 self.gt.append(gt.numpy())
+                fg = self.scene.last_fg
+                self.fg.append(np.zeros((H, W), bool) if fg is None else fg.numpy())
         self.grad, self.theta, self.istd = [], [], []
         for k in range(n_kf):
             g, t, s = oracle.gradient_prepass(self.im[k])
@@ -52,6 +56,15 @@ class Sequence:
 
     def neighbours(self, k, n):
         return self.scene.neighbours(k, self.n_kf, n)
+
+    def rot(self, k, n):
+        """median in-plane rotation of every (k, neighbour) pair, float32 degrees; None when the scene leaves it at 0"""
+        if not self.with_rot:
+            return None
+        return np.float32([self.scene.rot_deg(k, j) for j in self.neighbours(k, n)])
+
+    def rots(self, refs, n):
+        return None if not self.with_rot else np.stack([self.rot(k, n) for k in refs])
 
     def upload(self, eng, device_prepass=False):
         for k in range(self.n_kf):
@@ -68,7 +81,8 @@ def oracle_pipeline(oracle, seq, n, refs=None, rot=None):
     out = dict(k1_rho={}, k1_sigma={}, rho={}, sigma={}, chk={}, xyz={}, stats={})
     for k in refs:
         nb = seq.neighbours(k, n)
-        r, s, st = oracle.recon_search_fuse(seq.okf[k], [seq.okf[j] for j in nb], rot, seq.min_depth, seq.max_depth)
+        rk = seq.rot(k, n) if rot is None else rot
+        r, s, st = oracle.recon_search_fuse(seq.okf[k], [seq.okf[j] for j in nb], rk, seq.min_depth, seq.max_depth)
         out["k1_rho"][k], out["k1_sigma"][k], out["stats"][k] = r, s, st
         r2, s2 = oracle.intra_check(r, s)
         r3, s3 = oracle.intra_grow(r2, s2, seq.grad[k])

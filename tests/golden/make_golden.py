@@ -8,7 +8,7 @@ output of the oracle for every keyframe:  search+fuse (K1), intra check+grow (K3
 check with snapshot semantics (K4) as float32 bit patterns; the gradient inputs and the point set
 (K5) as SHA-256 digests.
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py [name ...]   # rewrites tests/golden/*.npz (all, or the named ones)
 """
 import os
 import sys
@@ -22,10 +22,13 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FIXTURES = [
-    # name, W, H, n_kf, n_nbr, seed, disparity_px
-    ("plane_64x48_n7", 64, 48, 8, 7, 0x5EED0101, 2.6),
-    ("plane_160x120_n7", 160, 120, 8, 7, 0x5EED0102, 2.6),
-    ("plane_96x80_n20", 96, 80, 21, 20, 0x5EED0103, 1.5),
+    # name, W, H, n_kf, n_nbr, seed, disparity_px, scene options
+    ("plane_64x48_n7", 64, 48, 8, 7, 0x5EED0101, 2.6, {}),
+    ("plane_160x120_n7", 160, 120, 8, 7, 0x5EED0102, 2.6, {}),
+    ("plane_96x80_n20", 96, 80, 21, 20, 0x5EED0103, 1.5, {}),
+    # App. D's second plane strip (a depth discontinuity with occluding edges) and keyframes rolled by up to +-5 degrees:
+    # pairs rotated against each other by up to 10 degrees, with the matching median rotations (PM.cc:170-179)
+    ("strip_roll_160x120_n7", 160, 120, 8, 7, 0x5EED0104, 3.0, {"strip": True, "roll_deg": 5.0}),
 ]
 
 
@@ -40,8 +43,11 @@ def main():
     from common import Sequence, oracle_inter, oracle_pipeline
     pkg = sdm_pkg.load()
     oracle = Oracle("strict")
-    for name, W, H, n_kf, n, seed, disp in FIXTURES:
-        seq = Sequence(pkg, oracle, W, H, n_kf, seed, disparity_px=disp)
+    only = sys.argv[1:]
+    for name, W, H, n_kf, n, seed, disp, opts in FIXTURES:
+        if only and name not in only:
+            continue
+        seq = Sequence(pkg, oracle, W, H, n_kf, seed, disparity_px=disp, **opts)
         maps = oracle_pipeline(oracle, seq, n)
         chk, xyz = oracle_inter(oracle, seq, n, maps)
         out = dict(
@@ -63,6 +69,12 @@ def main():
             candidates=np.array([maps["stats"][k]["candidates"] for k in range(n_kf)], dtype=np.int64),
             fused=np.array([maps["stats"][k]["fused"] for k in range(n_kf)], dtype=np.int64),
         )
+        if opts:
+            out["strip"] = np.int64(1 if opts.get("strip") else 0)
+            out["roll_deg"] = np.float64(opts.get("roll_deg", 1.0))
+            out["rot"] = seq.rots(range(n_kf), n)
+            out["gt_rho"] = np.stack(seq.gt).astype(np.float32)
+            out["fg"] = np.stack([seq.fg[k] for k in range(n_kf)])
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         kept = int(sum((chk[k] > 1e-6).sum() for k in range(n_kf)))

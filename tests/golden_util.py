@@ -28,4 +28,13 @@ def sha(a):
 def sequence_from(pkg, oracle, g):
     from common import Sequence
     return Sequence(pkg, oracle, g["W"], g["H"], g["n_kf"], g["seed"], disparity_px=float(g["disparity_px"]),
-                    images=g["im"])
+                    images=g["im"], **scene_options(g))
+
+
+def scene_options(g):
+    return dict(strip=bool(int(g["strip"])), roll_deg=float(g["roll_deg"])) if "roll_deg" in g else {}
+
+
+def rots(g):
+    """[n_kf, n] median in-plane rotations of the fixture's pairs (PM.cc:170-179), or None (App. D: 0)"""
+    return g["rot"] if "rot" in g else None

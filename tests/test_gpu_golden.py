@@ -24,12 +24,13 @@ def test_engine_matches_golden(pkg, oracle, gpu_ok, name, device_prepass):
         seq = gu.sequence_from(pkg, oracle, g)  # oracle pre-pass only supplies the INPUT planes here
         seq.upload(eng)
     refs = list(range(n_kf))
-    eng.search_fuse(refs, g["nbrs"], float(g["min_depth"]), float(g["max_depth"]))
+    rots = gu.rots(g)
+    eng.search_fuse(refs, g["nbrs"], float(g["min_depth"]), float(g["max_depth"]), rot=rots)
     for k in refs:
         r, s = eng.download_depth(k)
         assert_bit_equal(r, g["k1_rho"][k], "K1 rho kf %d" % k)
         assert_bit_equal(s, g["k1_sigma"][k], "K1 sigma kf %d" % k)
-    eng.recon(refs, g["nbrs"], float(g["min_depth"]), float(g["max_depth"]))
+    eng.recon(refs, g["nbrs"], float(g["min_depth"]), float(g["max_depth"]), rot=rots)
     eng.inter_check(refs, g["nbrs"])
     eng.pointset(refs, source=1)
     for k in refs:

@@ -190,3 +190,73 @@ def test_rgb_batch_equals_single_uploads(pkg, oracle, gpu_ok):
             assert one.active_list(k)[1] == bat.active_list(k)[1]
     one.close()
     bat.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_streaming_order_equals_serial_order(pkg, oracle, gpu_ok, overlap):
+    """blocks of keyframes arrive continuously (src/Tracking.cc:266-271): block i is stepped while block i+1 is uploaded
+    into the other half of the slot pool (bench.py's value_streaming).  Every block's maps equal the ones an engine gets
+    that uploads and steps the same block on its own."""
+    W, H, n_blk, n = 160, 120, 8, 5
+    seqs = [Sequence(pkg, oracle, W, H, n_blk, 0x5EED0E00 + b, disparity_px=2.6 + b) for b in range(4)]
+    refs = list(range(n_blk))
+    nbrs = [seqs[0].neighbours(k, n) for k in refs]
+
+    def serial(seq):
+        eng = pkg.Engine(W, H, n_blk, max_neighbours=n)
+        eng.upload_images_batch(refs, seq.im, seq.K, seq.Tcw)
+        eng.recon(refs, nbrs, seq.min_depth, seq.max_depth)
+        eng.inter_check_pointset(refs, nbrs, commit=False)
+        out = [(eng.download_depth(k), eng.download_checked(k), eng.download_pointset(k)) for k in refs]
+        eng.close()
+        return out
+
+    want = [serial(s) for s in seqs]
+    eng = pkg.Engine(W, H, 2 * n_blk, max_neighbours=n)
+    eng.set_ingest_overlap(overlap)  # (8 keyframes of 160x120 go through in four chunks: the overlapped path is taken)
+    half = lambda b: [k + (b & 1) * n_blk for k in refs]
+    hn = lambda b: [[j + (b & 1) * n_blk for j in row] for row in nbrs]
+    got = {}
+    eng.upload_images_batch(half(0), seqs[0].im, seqs[0].K, seqs[0].Tcw)
+    for b in range(len(seqs)):
+        eng.recon(half(b), hn(b), seqs[b].min_depth, seqs[b].max_depth)         # queued, not awaited ...
+        eng.inter_check_pointset(half(b), hn(b), commit=False)
+        if b + 1 < len(seqs):                                                   # ... while the next block comes in
+            eng.upload_images_batch(half(b + 1), seqs[b + 1].im, seqs[b + 1].K, seqs[b + 1].Tcw)
+        # block b's results are read back after block b+1's upload was queued: the upload went to the OTHER half
+        got[b] = [(eng.download_depth(k), eng.download_checked(k), eng.download_pointset(k)) for k in half(b)]
+    for b in range(len(seqs)):
+        for i, k in enumerate(refs):
+            assert_bit_equal(got[b][i][0][0], want[b][i][0][0], "block %d rho kf %d" % (b, k))
+            assert_bit_equal(got[b][i][0][1], want[b][i][0][1], "block %d sigma kf %d" % (b, k))
+            assert_bit_equal(got[b][i][1], want[b][i][1], "block %d checked kf %d" % (b, k))
+            assert_bit_equal(got[b][i][2], want[b][i][2], "block %d xyz kf %d" % (b, k))
+    eng.close()
+
+
+def test_overlapped_ingest_into_slots_in_use(pkg, oracle, gpu_ok):
+    """overlapped ingest must still be ordered behind compute calls that READ the slots it overwrites: a block is re-uploaded
+    with different images into the very slots a queued reconstruction uses; the reconstruction sees the old images, the next
+    one the new ones"""
+    W, H, n_blk, n = 160, 120, 8, 5
+    a = Sequence(pkg, oracle, W, H, n_blk, 0x5EED0E10)
+    b = Sequence(pkg, oracle, W, H, n_blk, 0x5EED0E11, disparity_px=4.0)
+    refs = list(range(n_blk))
+    nbrs = [a.neighbours(k, n) for k in refs]
+    eng = pkg.Engine(W, H, n_blk, max_neighbours=n)
+    eng.set_ingest_overlap(True)
+    eng.upload_images_batch(refs, a.im, a.K, a.Tcw)
+    for rep in range(3):
+        eng.recon(refs, nbrs, a.min_depth, a.max_depth)          # queued on the compute stream ...
+        eng.upload_images_batch(refs, b.im, b.K, b.Tcw)           # ... and its inputs overwritten right behind it
+        eng.recon(refs, nbrs, b.min_depth, b.max_depth)
+        got_b = [eng.download_depth(k) for k in refs]
+        eng.upload_images_batch(refs, a.im, a.K, a.Tcw)
+        eng.recon(refs, nbrs, a.min_depth, a.max_depth)
+        got_a = [eng.download_depth(k) for k in refs]
+        for k in refs:
+            for seq, got in ((a, got_a), (b, got_b)):
+                r, s, _ = oracle.semi_dense_recon(seq.okf[k], [seq.okf[j] for j in nbrs[k]], None, seq.min_depth, seq.max_depth)
+                assert_bit_equal(got[k][0], r, "rep %d rho kf %d" % (rep, k))
+                assert_bit_equal(got[k][1], s, "rep %d sigma kf %d" % (rep, k))
+    eng.close()

@@ -46,6 +46,25 @@ def test_synthetic_images_regenerate(pkg, oracle):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
+def test_strip_scene_recovers_both_planes(pkg, oracle):
+    """the two-plane fixture: the checked depths recover the analytic ground truth on the background AND on the foreground
+    strip, the regenerated rotations are the fixture's, and the occluding edges cost support (pixels next to the strip whose
+    neighbours see the other plane) rather than accuracy"""
+    g = gu.load("strip_roll_160x120_n7")
+    from common import Sequence
+    seq = Sequence(pkg, oracle, g["W"], g["H"], g["n_kf"], g["seed"], disparity_px=float(g["disparity_px"]), **gu.scene_options(g))
+    assert_bit_equal(seq.rots(range(g["n_kf"]), g["n"]), g["rot"], "median in-plane rotations")
+    assert np.abs(g["rot"]).max() > 3.0
+    for k in (2, 4, 5):
+        kept = g["chk"][k] > 1e-6
+        for name, plane in (("background", ~g["fg"][k]), ("strip", g["fg"][k])):
+            m = kept & plane
+            assert m.sum() > 150, (name, k, int(m.sum()))
+            err = np.abs(g["chk"][k][m] - g["gt_rho"][k][m])
+            assert np.median(err) < 8e-3, (name, k, float(np.median(err)))
+        assert abs(float(g["gt_rho"][k][g["fg"][k]].mean()) - 1.0 / 0.75) < 0.02
+
+
 def test_golden_accuracy_vs_ground_truth(pkg, oracle):
     """sanity of the whole restatement: the fused inverse depths recover the analytic plane"""
     g = gu.load("plane_160x120_n7")

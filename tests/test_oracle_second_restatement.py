@@ -37,7 +37,8 @@ def test_second_restatement_matches_oracle_and_golden(pkg, oracle, name):
             assert_bit_equal(pr.R21, np.array(po.R21[:]).reshape(3, 3), "R21")
             assert_bit_equal(pr.t21, np.array(po.t21[:]), "t21")
             assert_bit_equal(pr.F12, np.array(po.F12[:]).reshape(3, 3), "F12")
-        r, s, st = np_pm.recon_search_fuse(kfs[k], [kfs[j] for j in nb], pairs, seq.min_depth, seq.max_depth)
+        r, s, st = np_pm.recon_search_fuse(kfs[k], [kfs[j] for j in nb], pairs, seq.min_depth, seq.max_depth,
+                                           rots=seq.rot(k, n))  # (None for the one-plane fixtures: rot = 0)
         assert_bit_equal(r, g["k1_rho"][k], "%s K1 rho kf %d" % (name, k))      # scan + refine + Eq. 8/9 + fusion
         assert_bit_equal(s, g["k1_sigma"][k], "%s K1 sigma kf %d" % (name, k))
         assert st["searches"] == g["searches"][k] and st["candidates"] == g["candidates"][k]  # same scan loops
