@@ -289,7 +289,7 @@ def measure(wl, steps, warmup, barrier, exchange, transport, reduce_max=None):
     return dt, timing, dt_c, timing_c, n_pre
 
 
-def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False, outliers=0, spread=0.1):
+def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False, outliers=0, spread=0.1, strip=False, roll=1.0):
     """HBM-side bytes of one k_search_fuse launch from a committed PMC run (tools/pmc.sh: rocprofv3 cannot
     run inside bench.py).  Only a file whose workload AND kernel-source hash match this build is used."""
     src = source_hash()
@@ -306,8 +306,8 @@ def committed_traffic(res, kfs, nbrs, disparity, k1_launches, steps, noise=False
         w = t.get("workload", {})
         if t.get("src_hash") == src and \
                 (w.get("res"), w.get("kfs"), w.get("nbrs"), w.get("disparity"), bool(w.get("noise", False)),
-                 int(w.get("outliers", 0)), float(w.get("spread", 0.1))) == (res, kfs, nbrs, disparity, bool(noise),
-                                                                             int(outliers), float(spread)):
+                 int(w.get("outliers", 0)), float(w.get("spread", 0.1)), w.get("scene", "plane"), float(w.get("roll", 1.0))) == (
+                    res, kfs, nbrs, disparity, bool(noise), int(outliers), float(spread), "strip" if strip else "plane", float(roll)):
             return t["traffic_bytes_per_launch"]
     return None
 
@@ -333,7 +333,8 @@ def run_extra(pkg, torch, res, kfs, N, disparity, steps, warmup, local_rank, bar
     dt, timing, dt_c, timing_c, _ = measure(wl, steps, warmup, barrier, "halo", "torch")
     plain = not (noise or outliers or strip) and spread == 0.1 and roll == 1.0
     rf, k1_avg = roofline(wl, timing, steps, committed_traffic(res, kfs, N, disparity, timing["search_fuse"][1], steps,
-                                                               noise=noise, outliers=outliers, spread=spread))
+                                                               noise=noise, outliers=outliers, spread=spread, strip=strip,
+                                                               roll=roll))
     rf_c, _ = roofline(wl, timing_c, steps, None)
     rf["frac_cold"] = rf_c["frac"]
     rf["launch_ms_cold"] = rf_c["launch_ms"]
@@ -553,7 +554,8 @@ def main():
     value = P * n_total * args.steps / dt / 1e6
     rf, k1_avg_ms = roofline(wl, timing, args.steps,
                              committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps,
-                                               noise=args.noise, outliers=args.outliers, spread=args.prior_spread)
+                                               noise=args.noise, outliers=args.outliers, spread=args.prior_spread,
+                                               strip=(args.scene == "strip"), roll=args.roll)
                              if world == 1 else None)
     rf_cold, _ = roofline(wl, timing_cold, args.steps, None)
     rf["frac_cold"] = rf_cold["frac"]  # the same K steps after only the W warm-up steps (no pre-warm phase)
@@ -699,9 +701,9 @@ def main():
 
 def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
     """Sustained ingest + compute (frames arrive continuously in the fork: src/Tracking.cc:266-271 -> Modeler.cc:1496-1514):
-    the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch into the OTHER half of a
-    double-sized slot pool, its staging and H2D copies running while the previous block's step executes -- then that block is
-    stepped (K1-K5).  Returns Mpix*KF/s over `iters` blocks, wall clock, everything included; the maps of the last two blocks
+    the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch, two blocks ahead, into the
+    half of a double-sized slot pool that the block being stepped occupies (overlapped ingest: sdm_set_ingest_overlap), its
+    staging and H2D copies running while that step executes -- then that block is stepped (K1-K5).  Returns Mpix*KF/s over `iters` blocks, wall clock, everything included; the maps of the last two blocks
     are compared with a serial upload-then-step of the same images (bit-equal, or the figure is not reported)."""
     import numpy as np
     pl = wl.pl
@@ -745,9 +747,13 @@ def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
     eng.synchronize()
     t0 = time.perf_counter()
     eng.upload_images_batch(slots[0], ims, wl.K, poses)
+    eng.upload_images_batch(slots[1], ims, wl.K, poses)
     for i in range(iters):
-        step(i & 1)                                                       # asynchronous: returns when the launches are queued
-        eng.upload_images_batch(slots[(i + 1) & 1], ims, wl.K, poses)     # the next block, while this one computes
+        step(i & 1)  # asynchronous: returns when the launches are queued (this block's list lengths arrived a step ago)
+        # block i+2 into the half block i occupies: the engine orders its device work behind block i's step (the slots'
+        # last use) while the host stages and copies it during that step -- the host never waits for the GPU here
+        if i + 2 < iters:  # (every stepped block is uploaded exactly once: two before the loop, iters - 2 inside it)
+            eng.upload_images_batch(slots[i & 1], ims, wl.K, poses)
     eng.synchronize()
     dt = time.perf_counter() - t0
     ok = True

@@ -110,10 +110,12 @@ struct sdm_ctx {
         hipEvent_t copied = nullptr;    // this chunk's H2D copies (upload stream) have finished
         hipEvent_t consumed = nullptr;  // the kernels that read d_img / d_src / d_items (compute stream) have finished
         bool copied_pending = false, consumed_pending = false;
-    } ing[2];
+    } ing[4];  // (four: a 64-keyframe block goes through in four chunks without a copy waiting for an earlier chunk's kernels)
+    static constexpr int ING_BUFS = 4;
     int ing_next = 0;
     size_t src_bytes = 0;
     hipStream_t up_stream = nullptr;
+    hipStream_t pre_stream = nullptr;  // overlapped ingest: the pre-pass kernels (the copies stay on up_stream: a copy never queues behind a kernel)
     unsigned long long* d_part = nullptr;      // [ing_cap][ntiles][PART_WORDS] per-tile partial sums
     unsigned long long* d_seg_mask = nullptr;  // [ing_cap][nseg] lambdaG-gate lane mask of every 64-pixel row segment
     int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
@@ -135,8 +137,13 @@ struct sdm_ctx {
     hipEvent_t use_ev[USE_RING] = {};
     unsigned long long use_next = 1;              // id of the next compute call (0 = never used)
     std::vector<unsigned long long> slot_use;     // [max_keyframes] id of the last compute call that touched the slot
-    hipEvent_t ev_ingest = nullptr, ev_counts = nullptr;
-    bool counts_on_upload_stream = false;         // the pending list-length read-back was queued on the upload stream
+    hipEvent_t ev_ingest = nullptr;
+    // list-length read-backs of overlapped uploads: one event per upload call (a ring), and per slot the call whose read-back
+    // it still awaits -- a compute call waits for ITS slots' lengths only, not for an upload two blocks ahead
+    static constexpr int CNT_RING = 8;
+    hipEvent_t cnt_ev[CNT_RING] = {};
+    unsigned long long cnt_next = 1, cnt_done = 0;   // ids of the next / the newest completed overlapped upload
+    std::vector<unsigned long long> slot_cnt;        // [max_keyframes] id of the upload whose count the slot awaits (0: none)
     unsigned long long misc_last = 0;             // id of the last compute-stream operation that wrote slots without naming
                                                   // them through a table set (uploads on the compute stream, list rebuilds, ...)
     bool validated = false;                    // validate_params: the last non-default parameter set checked on the device ...
@@ -340,12 +347,8 @@ int ingest_counts(sdm_ctx* c, int m, const int* slots, hipStream_t ks = nullptr)
         for (int i = 0; i < m; i++)
             HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost, ks));
     }
-    c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
-    if (ks != c->stream) {
-        HIP_TRY(hipEventRecord(c->ev_counts, ks));
-        c->counts_on_upload_stream = true;
-    }
-    return SDM_OK;
+    if (ks == c->stream) c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
+    return SDM_OK;                                   // (overlapped uploads: per-slot bookkeeping in ingest_images_impl)
 }
 // the three launches of a chunk on the compute stream (+ k_ingest_batch for colour / distorted frames)
 int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q, hipStream_t ks = nullptr)
@@ -382,7 +385,7 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
     for (int i0 = 0; i0 < n; i0 += c->ing_cap) {
         const int m = std::min(c->ing_cap, n - i0);
         const int b = c->ing_next;
-        c->ing_next ^= 1;
+        c->ing_next = (c->ing_next + 1) % sdm_ctx::ING_BUFS;
         if ((rc = ingest_acquire(c, b, c->stream))) return rc;
         for (int i = 0; i < m; i++) {
             IngestItem& it = c->ing[b].h_items[i];
@@ -412,13 +415,34 @@ int build_active(sdm_ctx* c, int slot) { return rebuild_lists(c, 1, &slot); }
 int sync_counts(sdm_ctx* c)
 {
     if (c->counts_pending) {
-        if (c->counts_on_upload_stream) {  // (overlapped ingest: the compute stream may be busy with an earlier step)
-            HIP_TRY(hipEventSynchronize(c->ev_counts));
-            c->counts_on_upload_stream = false;
-        } else {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->counts_pending = false;
+    }
+    if (c->cnt_done + 1 < c->cnt_next) {  // every overlapped upload's read-back (they complete in order on one stream)
+        HIP_TRY(hipStreamSynchronize(c->pre_stream));
+        c->cnt_done = c->cnt_next - 1;
+    }
+    return SDM_OK;
+}
+// ... of these slots only (stage_tables): an overlapped upload that is still waiting for its turn behind an earlier step does
+// not hold up a compute call on OTHER slots
+int sync_counts_for(sdm_ctx* c, int n_a, const int* a, size_t n_b, const int* b)
+{
+    if (c->counts_pending) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->counts_pending = false;
+    }
+    unsigned long long g = 0;
+    for (int i = 0; i < n_a; i++) g = std::max(g, c->slot_cnt[(size_t)a[i]]);
+    for (size_t i = 0; i < n_b; i++) g = std::max(g, c->slot_cnt[(size_t)b[i]]);
+    if (g > c->cnt_done) {
+        if (c->cnt_next - g >= (unsigned long long)sdm_ctx::CNT_RING) {  // its event was recycled: wait for all of them
+            HIP_TRY(hipStreamSynchronize(c->pre_stream));
+            c->cnt_done = c->cnt_next - 1;
+        } else {
+            HIP_TRY(hipEventSynchronize(c->cnt_ev[g % sdm_ctx::CNT_RING]));
+            c->cnt_done = g;
+        }
     }
     return SDM_OK;
 }
@@ -550,7 +574,7 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
             for (size_t i = 0; i < (size_t)n_ref * (size_t)n; i++) look(nbr_slots[i]);
         if (!stale.empty() && (rc = rebuild_lists(c, (int)stale.size(), stale.data()))) return rc;
     }
-    if ((rc = sync_counts(c))) return rc;  // callers size their grids from h_act_count
+    if ((rc = sync_counts_for(c, n_ref, ref_slots, (size_t)n_ref * (size_t)n, nbr_slots))) return rc;  // grids follow h_act_count
 
     const size_t np = (size_t)n_ref * (size_t)n;
     auto matches = [&](const sdm_ctx::TableKey& k) {
@@ -810,6 +834,7 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->chk_sparse.assign(K, 1);  // planes start zeroed
     c->xyz_sparse.assign(K, 1);
     c->slot_use.assign(K, 0);
+    c->slot_cnt.assign(K, 0);
 
     int rc = SDM_OK;
     auto bail = [&](int code) {
@@ -878,16 +903,19 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
             // NEXT TO a step that fills the GPU (at equal priority they waited behind K1's 60 000 workgroups: measured)
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p) != hipSuccess)
+            if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p) != hipSuccess ||
+                hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, hi_p) != hipSuccess)
                 return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
         }
-        if (hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_counts, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming) != hipSuccess)
             return bail(fail(SDM_EHIP, "hipEventCreate failed"));
+        for (int i = 0; i < sdm_ctx::CNT_RING; i++)
+            if (hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(SDM_EHIP, "hipEventCreate failed"));
         for (int i = 0; i < sdm_ctx::USE_RING; i++)
             if (hipEventCreateWithFlags(&c->use_ev[i], hipEventDisableTiming) != hipSuccess)
                 return bail(fail(SDM_EHIP, "hipEventCreate failed"));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
             sdm_ctx::IngestBuf& B = c->ing[b];
             if ((rc = dev_alloc(&B.d_img, (size_t)c->ing_cap * c->P)) || (rc = host_alloc(&B.h_ring, (size_t)c->ing_cap * c->P)) ||
                 (rc = dev_alloc(&B.d_items, (size_t)c->ing_cap)) || (rc = host_alloc(&B.h_items, (size_t)c->ing_cap)))
@@ -973,7 +1001,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_grow_pix);
     (void)hipFree(c->d_grow_val);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
         sdm_ctx::IngestBuf& B = c->ing[b];
         (void)hipFree(B.d_img);
         (void)hipFree(B.d_src);
@@ -985,8 +1013,13 @@ void sdm_destroy(sdm_ctx* c)
         if (B.consumed) (void)hipEventDestroy(B.consumed);
     }
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->pre_stream) {
+        (void)hipStreamSynchronize(c->pre_stream);
+        (void)hipStreamDestroy(c->pre_stream);
+    }
     if (c->ev_ingest) (void)hipEventDestroy(c->ev_ingest);
-    if (c->ev_counts) (void)hipEventDestroy(c->ev_counts);
+    for (int i = 0; i < sdm_ctx::CNT_RING; i++)
+        if (c->cnt_ev[i]) (void)hipEventDestroy(c->cnt_ev[i]);
     for (int i = 0; i < sdm_ctx::USE_RING; i++)
         if (c->use_ev[i]) (void)hipEventDestroy(c->use_ev[i]);
     (void)hipFree(c->d_part);
@@ -1197,7 +1230,7 @@ int ensure_src_buffers(sdm_ctx* c)
 {
     if (c->ing[0].d_src) return SDM_OK;
     int rc;
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
         if ((rc = dev_alloc(&c->ing[b].d_src, c->src_bytes))) return rc;
         if ((rc = host_alloc(&c->ing[b].h_src, c->src_bytes))) return rc;
     }
@@ -1247,7 +1280,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     // compute stream.  Not while an exchange is in flight (its transfers are ordered against the compute stream only) and not
     // for images that live in device memory (whatever produced them is ordered against the compute stream only).
     const bool overlap = c->ingest_overlap && n_chunks > 1 && !on_device && !c->xchg_pending && !c->ag_open;
-    const hipStream_t ks = overlap ? c->up_stream : c->stream;
+    const hipStream_t ks = overlap ? c->pre_stream : c->stream;
     if (overlap) {
         unsigned long long id = c->misc_last;
         for (int i = 0; i < n; i++) id = std::max(id, c->slot_use[(size_t)slots[i]]);
@@ -1256,7 +1289,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
                 id = c->use_next++;
                 HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
             }
-            HIP_TRY(hipStreamWaitEvent(c->up_stream, c->use_ev[id % sdm_ctx::USE_RING], 0));
+            HIP_TRY(hipStreamWaitEvent(c->pre_stream, c->use_ev[id % sdm_ctx::USE_RING], 0));
         }
     }
     double tdbg[6] = {0, 0, 0, 0, 0, 0};
@@ -1280,7 +1313,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
         const int m = std::min(cap, n - i0);
         failed_from = i0;
         const int b = c->ing_next;
-        c->ing_next ^= 1;
+        c->ing_next = (c->ing_next + 1) % sdm_ctx::ING_BUFS;
         sdm_ctx::IngestBuf& B = c->ing[b];
         if (dbg) tdbg[0] = now();
         if ((rc = ingest_acquire(c, b, cs))) return bail(rc);
@@ -1339,7 +1372,10 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
     // in place are awaited here (the pre-pass kernels are not)
     if (overlap) {  // everything queued on the compute stream from here on sees the new keyframes
-        HIP_TRY(hipEventRecord(c->ev_ingest, c->up_stream));
+        const unsigned long long g = c->cnt_next++;
+        HIP_TRY(hipEventRecord(c->cnt_ev[g % sdm_ctx::CNT_RING], c->pre_stream));  // (behind the last chunk's read-back)
+        for (int i = 0; i < n; i++) c->slot_cnt[(size_t)slots[i]] = g;
+        HIP_TRY(hipEventRecord(c->ev_ingest, c->pre_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ingest, 0));
     } else if ((rc = note_misc(c))) {
         return rc;
@@ -2229,8 +2265,9 @@ int sdm_set_ingest_overlap(sdm_ctx* c, int on)
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));  // a clean start: nothing in flight that the tracking has not seen
     if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->pre_stream) HIP_TRY(hipStreamSynchronize(c->pre_stream));
     c->counts_pending = false;
-    c->counts_on_upload_stream = false;
+    c->cnt_done = c->cnt_next - 1;
     c->ingest_overlap = on != 0;
     std::fill(c->slot_use.begin(), c->slot_use.end(), 0ull);
     c->misc_last = 0;

@@ -34,11 +34,12 @@ for overlap in (False, True):
     ts, tu = [], []
     t0 = time.perf_counter()
     eng.upload_images_batch(slots[0], ims, wl.K, poses)
+    eng.upload_images_batch(slots[1], ims, wl.K, poses)
     for i in range(20):
         a = time.perf_counter()
         step(i & 1)
         b = time.perf_counter()
-        eng.upload_images_batch(slots[(i + 1) & 1], ims, wl.K, poses)
+        eng.upload_images_batch(slots[i & 1], ims, wl.K, poses)  # two blocks ahead, into the half being stepped
         c = time.perf_counter()
         ts.append(b - a); tu.append(c - b)
     eng.synchronize()

@@ -47,9 +47,12 @@ if k1:
         ap.add_argument("--disparity", type=float, default=2.6)
         ap.add_argument("--noise", action="store_true")
         ap.add_argument("--outliers", type=int, default=0)
+        ap.add_argument("--prior-spread", type=float, default=0.1)
+        ap.add_argument("--scene", default="plane")
+        ap.add_argument("--roll", type=float, default=1.0)
         a, _ = ap.parse_known_args(os.environ.get("PMC_BENCH_ARGS", "").split())
         out["workload"] = {"res": a.res, "kfs": a.kfs, "nbrs": a.nbrs, "disparity": a.disparity, "noise": a.noise,
-                           "outliers": a.outliers}
+                           "outliers": a.outliers, "spread": a.prior_spread, "scene": a.scene, "roll": a.roll}
         out["src_hash"] = bench.source_hash()
         out["source"] = "tools/pmc.sh (rocprofv3 --pmc, one counter group per pass)"
         json.dump(out, open(root + "/traffic.json", "w"), indent=1)
