@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--cpu-kfs", type=int, default=48, help="keyframes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the sustained ingest + compute figure (N=1 only)")
     ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather", "allgather_late", "allgather_full"],
                     help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: "
                          "allgather = RCCL all-gather of the maps that cross ranks (every rank's boundary keyframes, "
@@ -508,7 +509,7 @@ def main():
         eng.host_free(block)
 
     streaming = None
-    if rank == 0 and world == 1 and wl.images and not args.outliers:
+    if rank == 0 and world == 1 and wl.images and not args.outliers and not args.no_streaming:
         import gc
         gc.collect()
         gc.disable()  # (a full collection of this interpreter's heap costs ~40 ms: profiles/r05_upload_spikes.txt)

@@ -67,6 +67,17 @@ def test_fuzz_whole_path(pkg, oracle, gpu_ok, mode, seed):
     W, H, n_kf, n = 72, 56, 7, 5
     case = make_case(rng, oracle, W, H, n_kf, mode)
     eng = pkg.Engine(W, H, n_kf, max_neighbours=n)
+    if seed % 3 == 0:
+        # every third case runs under thresholds other than PM.h:38-49's defaults: the closed-form gates / approximate arg-min
+        # with run-time constants (validated on the device by sdm_set_params) or, where they do not hold, the reference statements
+        from pm_oracle import Oracle
+        oracle = Oracle("strict")
+        prm = dict(lambdaG=float(rng.choice([6.0, 8.0, 11.5])), lambdaL=float(rng.choice([80.0, 70.0, 45.5, 89.0, 95.0, -3.0])),
+                   lambdaTheta=float(rng.choice([45.0, 40.0, 12.25, 56.0, 120.0, 181.0, 0.0])),
+                   theta_var=float(rng.choice([0.23, 0.25, 0.05, 7.0])), lambdaN=int(rng.choice([3, 2, 4])))
+        for key, val in prm.items():
+            setattr(oracle.params, key, val)
+        eng.set_params(**prm)
     for k in range(n_kf):
         if k % 2:
             eng.upload_image(k, case["im"][k], case["K"][k], case["Tcw"][k])
