@@ -69,6 +69,8 @@ typedef struct {
     long long mask_steps; /* mask words those scans examined (lane steps) */
     long long mask_row_mismatch; /* self-check of the mask scan's row runs: must stay 0 */
     long long open_pixels; /* fusing pixels neither shortcut of InverseDepthHypothesisFusion settled: all-pairs count, PM.cc:598-626 */
+    long long table_stagings; /* host: compute calls whose slot / constant tables were not found in a cached set (K1 -> K4 -> K5
+                                 of one step share one; counted whether or not statistics are enabled) */
 } sdm_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -30,7 +30,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("searches", C.c_longlong), ("candidates", C.c_longlong), ("gate_pass", C.c_longlong),
                 ("hypotheses", C.c_longlong), ("fused", C.c_longlong), ("mask_waves", C.c_longlong),
-                ("mask_steps", C.c_longlong), ("mask_row_mismatch", C.c_longlong), ("open_pixels", C.c_longlong)]
+                ("mask_steps", C.c_longlong), ("mask_row_mismatch", C.c_longlong), ("open_pixels", C.c_longlong),
+                ("table_stagings", C.c_longlong)]
 
 
 def lib_path():

@@ -186,6 +186,7 @@ struct sdm_ctx {
     float *d_rot = nullptr, *d_mind = nullptr, *d_maxd = nullptr;
     long long *d_off = nullptr, *h_off = nullptr;  // 3 offset tables of n_ref: pool, scratch, record
     unsigned long long epoch = 1;  // bumped whenever poses, intrinsics, lists or slots change
+    long long table_stagings = 0;  // calls whose tables were not in a cached set (sdm_stats::table_stagings)
     RefConst* d_refs = nullptr;
     PairConst* d_pairs = nullptr;
 
@@ -609,6 +610,7 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
         if (c->sets[si].last_use < c->sets[victim].last_use) victim = si;
     }
     const size_t words = select_set(c, victim, n_ref, np);
+    c->table_stagings++;
     if ((rc = wait_tables(c))) return rc;  // only if that set was staged within the last few calls
     sdm_ctx::TableKey& k = c->sets[victim].key;
     k.valid = false;
@@ -642,6 +644,14 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     HIP_TRY(hipGetLastError());
     k.valid = true;
     k.has_consts = (n > 0) && mind && maxd;
+    k.n_ref = n_ref;
+    k.n = n;
+    k.epoch = c->epoch;
+    k.refs.assign(ref_slots, ref_slots + n_ref);
+    k.nbrs.assign(nbr_slots, nbr_slots + np);
+    k.rot.assign(h_rot, h_rot + np);
+    k.mind.assign(h_mind, h_mind + n_ref);
+    k.maxd.assign(h_maxd, h_maxd + n_ref);
     k.long_ranges = false;
     if (k.has_consts) {
         // The search range of PM.cc:877-910 at the principal point (xp = (0, 0, 1)), averaged over the call's pairs, restated on
@@ -1284,6 +1294,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     if (overlap) {
         unsigned long long id = c->misc_last;
         for (int i = 0; i < n; i++) id = std::max(id, c->slot_use[(size_t)slots[i]]);
+
         if (id != 0) {
             if (c->use_next - id >= (unsigned long long)sdm_ctx::USE_RING) {  // its event was recycled: wait for "now" instead
                 id = c->use_next++;
@@ -2298,6 +2309,8 @@ int sdm_get_stats(sdm_ctx* c, sdm_stats* out, int reset)
     out->mask_steps = (long long)v[6];
     out->mask_row_mismatch = (long long)v[7];
     out->open_pixels = (long long)v[8];
+    out->table_stagings = c->table_stagings;
+    if (reset) c->table_stagings = 0;
     if (reset) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(v), c->stream));
     return SDM_OK;
 }

@@ -36,7 +36,7 @@ def test_struct_layouts(pkg):
     # sdm_params {float,float,float,int,double} and sdm_config as laid out by the C compiler
     assert ctypes.sizeof(b.Params) == 24
     assert ctypes.sizeof(b.Config) == 48
-    assert ctypes.sizeof(b.Stats) == 72
+    assert ctypes.sizeof(b.Stats) == 80
     lib = pkg.load_library()
     p = b.Params()
     lib.sdm_default_params(ctypes.byref(p))

@@ -804,3 +804,24 @@ def test_search_fuse_with_outlier_hypotheses(pkg, oracle, gpu_ok, seq_mid, monke
             assert int(((nh > 3) & full).sum()) > 100, "some pixels must take the shortcut as well"
     assert open_px > 300, "the outlier neighbours must force the all-pairs path on many pixels (%d)" % open_px
     eng.close()
+
+
+def test_table_cache_serves_the_calls_of_a_step(pkg, oracle, gpu_ok, seq_mid):
+    """K1 -> K4 -> K5 of one step, and the same step again, find their slot / constant tables in a cached set (a step that
+    re-staged them per call would still be right, only slower: this pins the host-side cache)"""
+    n = 7
+    eng = make_engine(pkg, seq_mid, n)
+    refs = list(range(seq_mid.n_kf))
+    nbrs = [seq_mid.neighbours(k, n) for k in refs]
+    eng.get_stats(reset=True)
+    for _ in range(3):
+        eng.recon(refs, nbrs, seq_mid.min_depth, seq_mid.max_depth)
+        eng.inter_check_pointset(refs, nbrs, commit=False)
+        eng.pointset(refs, source=1)
+    assert eng.get_stats()["table_stagings"] == 1
+    eng.set_pose(2, seq_mid.Tcw[3])  # a pose change invalidates the cached constants: one more staging, then hits again
+    for _ in range(2):
+        eng.recon(refs, nbrs, seq_mid.min_depth, seq_mid.max_depth)
+        eng.inter_check_pointset(refs, nbrs, commit=False)
+    assert eng.get_stats()["table_stagings"] == 1
+    eng.close()
