@@ -702,10 +702,13 @@ def main():
 
 def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
     """Sustained ingest + compute (frames arrive continuously in the fork: src/Tracking.cc:266-271 -> Modeler.cc:1496-1514):
-    the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch, two blocks ahead, into the
-    half of a double-sized slot pool that the block being stepped occupies (overlapped ingest: sdm_set_ingest_overlap), its
-    staging and H2D copies running while that step executes -- then that block is stepped (K1-K5).  Returns Mpix*KF/s over `iters` blocks, wall clock, everything included; the maps of the last two blocks
-    are compared with a serial upload-then-step of the same images (bit-equal, or the figure is not reported)."""
+    the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch into the other half of a
+    double-sized slot pool, issued BEFORE the current block's step is queued: with the streaming ingest on
+    (sdm_set_ingest_overlap: twelve chunk buffers) its staging and H2D copies run while the previous step executes, its
+    pre-pass right behind that step, and the list lengths are back long before the block's own step is queued -- the host
+    never waits for the GPU, the GPU never for the host.  Returns Mpix*KF/s over `iters` blocks, wall clock, everything
+    included; the last blocks' maps are compared with a serial upload-then-step of the same images (bit-equal, or the figure
+    is not reported)."""
     import numpy as np
     pl = wl.pl
     ks = [k for k in pl["own"] if k in wl.images]
@@ -738,29 +741,25 @@ def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
     # serial reference: upload, step, read back
     eng.upload_images_batch(slots[0], ims, wl.K, poses)
     step(0)
-    want = [eng.download_checked(slots[0][i]) for i in (0, len(ks) // 2, len(ks) - 1)]
-    # streaming: block i is stepped while block i+1 is uploaded into the other half
+    probe = (0, len(ks) // 2, len(ks) - 1)
+    want = [eng.download_checked(slots[0][i]) for i in probe]
     for _ in range(2):  # warm-up round trips over both halves
-        eng.upload_images_batch(slots[1], ims, wl.K, poses)
-        step(1)
-        eng.upload_images_batch(slots[0], ims, wl.K, poses)
-        step(0)
+        for half in (1, 0):
+            eng.upload_images_batch(slots[half], ims, wl.K, poses)
+            step(half)
     eng.synchronize()
     t0 = time.perf_counter()
     eng.upload_images_batch(slots[0], ims, wl.K, poses)
-    eng.upload_images_batch(slots[1], ims, wl.K, poses)
     for i in range(iters):
-        step(i & 1)  # asynchronous: returns when the launches are queued (this block's list lengths arrived a step ago)
-        # block i+2 into the half block i occupies: the engine orders its device work behind block i's step (the slots'
-        # last use) while the host stages and copies it during that step -- the host never waits for the GPU here
-        if i + 2 < iters:  # (every stepped block is uploaded exactly once: two before the loop, iters - 2 inside it)
-            eng.upload_images_batch(slots[i & 1], ims, wl.K, poses)
+        if i + 1 < iters:  # the NEXT block first: copied while the previous step runs, pre-pass queued ahead of this step
+            eng.upload_images_batch(slots[(i + 1) & 1], ims, wl.K, poses)
+        step(i & 1)        # asynchronous: returns when the launches are queued (this block's list lengths arrived a step ago)
     eng.synchronize()
     dt = time.perf_counter() - t0
     ok = True
-    last = (iters - 1) & 1
-    for j, i in enumerate((0, len(ks) // 2, len(ks) - 1)):
-        ok = ok and np.array_equal(eng.download_checked(slots[last][i]).view(np.uint32), want[j].view(np.uint32))
+    for half in ((iters - 1) & 1, (iters - 2) & 1):  # the last two blocks: both halves are still intact
+        for j, i in enumerate(probe):
+            ok = ok and np.array_equal(eng.download_checked(slots[half][i]).view(np.uint32), want[j].view(np.uint32))
     if block is not None:
         eng.host_free(block)
     eng.close()

@@ -307,14 +307,14 @@ int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
  * wave and neighbour, from the wave's range lengths and line slopes; 1: always the batched scan; 2: always the scan over the
  * neighbour's gradient-gate bit plane.  Results are the same bit for bit in every mode (tests/test_gpu_longscan.py). */
 int sdm_set_scan_mode(sdm_ctx *ctx, int mode);
-/* Overlapped ingest (default off).  On: the device work of a batch upload of two or more chunks (sdm_upload_images_batch /
- * _rgb_batch: H2D copies, pre-pass kernels, list-length read-back) runs on the context's upload stream, ordered behind the
- * last compute call (sdm_recon, sdm_inter_check*, sdm_pointset, ...) that used any of the slots being overwritten -- not
- * behind everything queued on the compute stream -- and the compute stream waits for the upload.  A block of keyframes
- * arriving into slots that nothing in flight uses (double-buffered slot sets: frames arrive continuously in the fork,
- * src/Tracking.cc:266-271) then overlaps the step that is executing, and the calls that queue the next step do not wait for
- * the previous one to drain.  Results are the ones of the serial order (tests/test_gpu_ingest.py).  Uploads of a single chunk,
- * of device-resident images, and uploads issued while an exchange is in flight keep the serial order.  Host-blocking. */
+/* Streaming ingest (default off).  On: the batched uploads (sdm_upload_images_batch / _rgb_batch) get twelve chunk buffers
+ * instead of four, so the host staging and the H2D copies (upload stream) of up to three 64-keyframe blocks run ahead of
+ * their pre-pass kernels, which stay on the compute stream in call order.  A block uploaded BEFORE the previous block's step
+ * is queued (double-buffer the slot sets: bench.py streaming_rate; frames arrive continuously in the fork,
+ * src/Tracking.cc:266-271) is then copied while that step runs, pre-processed right behind it, and its list lengths are back
+ * before its own step is queued (every compute call waits for the list lengths of ITS slots only, with or without this
+ * switch).  Results are the serial order's by construction (one compute stream).  Costs 8 x the chunk size of device and
+ * pinned host memory (8 x 4.9 MB at 640x480).  Host-blocking when it allocates. */
 int sdm_set_ingest_overlap(sdm_ctx *ctx, int on);
 /* per-stage device time measured with HIP events recorded on the context's stream around each
  * stage's kernel launches (K1 = one k_search_fuse launch per sdm_recon/sdm_search_fuse call) */

@@ -89,7 +89,6 @@ struct sdm_ctx {
     unsigned grow_launch = 0;
     unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
     int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
-    bool counts_pending = false;   // a count read-back is still in flight on the stream (sync_counts)
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
     std::vector<char> chk_sparse, xyz_sparse;  // checked / xyz plane of the slot is zero outside its active list
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
@@ -110,12 +109,13 @@ struct sdm_ctx {
         hipEvent_t copied = nullptr;    // this chunk's H2D copies (upload stream) have finished
         hipEvent_t consumed = nullptr;  // the kernels that read d_img / d_src / d_items (compute stream) have finished
         bool copied_pending = false, consumed_pending = false;
-    } ing[4];  // (four: a 64-keyframe block goes through in four chunks without a copy waiting for an earlier chunk's kernels)
-    static constexpr int ING_BUFS = 4;
+    } ing[12];
+    static constexpr int ING_BUFS_MAX = 12;
+    int ing_bufs = 4;  // in use: four (a 64-keyframe block goes through in four chunks without a copy waiting for an earlier
+                       // chunk's kernels); twelve with overlapped ingest on (three blocks in flight), allocated when it is switched on
     int ing_next = 0;
     size_t src_bytes = 0;
     hipStream_t up_stream = nullptr;
-    hipStream_t pre_stream = nullptr;  // overlapped ingest: the pre-pass kernels (the copies stay on up_stream: a copy never queues behind a kernel)
     unsigned long long* d_part = nullptr;      // [ing_cap][ntiles][PART_WORDS] per-tile partial sums
     unsigned long long* d_seg_mask = nullptr;  // [ing_cap][nseg] lambdaG-gate lane mask of every 64-pixel row segment
     int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
@@ -128,24 +128,17 @@ struct sdm_ctx {
     int mrow = 0;                              // 32-bit words per image row: 2 * (tiles_x + 1) (the last two stay zero: the scan
                                                // reads the word after the one a column lies in)
     int scan_mode = 0;                         // DevParams::scan_mode (SDM_SCAN_MODE, read once in sdm_create)
-    // ---- overlapped ingest (sdm_set_ingest_overlap): a batch upload's device work -- copies, pre-pass, list lengths -- runs
-    // on the upload stream, ordered behind the last compute call that used any of the slots it overwrites (one event per
-    // compute call, a ring of them) instead of behind everything queued on the compute stream; the compute stream waits for
-    // the upload.  A block arriving into slots nothing in flight uses overlaps the step that is executing.
+    // ---- streaming ingest (sdm_set_ingest_overlap): with twelve chunk buffers instead of four, the host staging and the H2D
+    // copies of a batch upload (upload stream) run ahead of the pre-pass kernels (compute stream, in call order) by up to
+    // three 64-keyframe blocks: a block uploaded BEFORE the previous block's step is queued is copied while that step runs
     bool ingest_overlap = false;
-    static constexpr int USE_RING = 64;
-    hipEvent_t use_ev[USE_RING] = {};
-    unsigned long long use_next = 1;              // id of the next compute call (0 = never used)
-    std::vector<unsigned long long> slot_use;     // [max_keyframes] id of the last compute call that touched the slot
-    hipEvent_t ev_ingest = nullptr;
-    // list-length read-backs of overlapped uploads: one event per upload call (a ring), and per slot the call whose read-back
-    // it still awaits -- a compute call waits for ITS slots' lengths only, not for an upload two blocks ahead
-    static constexpr int CNT_RING = 8;
+    // list-length read-backs: one event per upload / list rebuild (a ring; all recorded on the compute stream, so they
+    // complete in order), and per slot the call whose read-back it still awaits -- a compute call waits for ITS slots'
+    // lengths only, not for the stream to drain (the step that is executing) nor for a block uploaded behind it
+    static constexpr int CNT_RING = 16;
     hipEvent_t cnt_ev[CNT_RING] = {};
-    unsigned long long cnt_next = 1, cnt_done = 0;   // ids of the next / the newest completed overlapped upload
-    std::vector<unsigned long long> slot_cnt;        // [max_keyframes] id of the upload whose count the slot awaits (0: none)
-    unsigned long long misc_last = 0;             // id of the last compute-stream operation that wrote slots without naming
-                                                  // them through a table set (uploads on the compute stream, list rebuilds, ...)
+    unsigned long long cnt_next = 1, cnt_done = 0;   // ids of the next / the newest completed read-back
+    std::vector<unsigned long long> slot_cnt;        // [max_keyframes] id of the read-back the slot's length awaits (0: none)
     bool validated = false;                    // validate_params: the last non-default parameter set checked on the device ...
     sdm_params validated_prm{};
     int validated_closed = 0, validated_approx = 0;  // ... and what held for it
@@ -325,9 +318,9 @@ int ingest_acquire(sdm_ctx* c, int b, hipStream_t copy_stream)
 }
 // the chunk's item table goes up behind whatever image copies were queued on the upload stream; the compute stream waits
 // for all of it
-int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream, hipStream_t ks = nullptr)
+int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream)
 {
-    if (!ks) ks = c->stream;
+    const hipStream_t ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, copy_stream));
     HIP_TRY(hipEventRecord(B.copied, copy_stream));
@@ -336,25 +329,32 @@ int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream, hipStream_
     return SDM_OK;
 }
 // list lengths of the chunk's slots -> pinned host mirror (one copy when the slots are consecutive)
-int ingest_counts(sdm_ctx* c, int m, const int* slots, hipStream_t ks = nullptr)
+int ingest_counts(sdm_ctx* c, int m, const int* slots)
 {
-    if (!ks) ks = c->stream;
     bool run = true;
     for (int i = 1; i < m; i++) run = run && slots[i] == slots[0] + i;
     if (run) {
         HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[0]], c->d_act_count + slots[0], sizeof(int) * (size_t)m,
-                               hipMemcpyDeviceToHost, ks));
+                               hipMemcpyDeviceToHost, c->stream));
     } else {
         for (int i = 0; i < m; i++)
-            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost, ks));
+            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost,
+                                   c->stream));
     }
-    if (ks == c->stream) c->counts_pending = true;  // the host reads h_act_count only after sync_counts()
-    return SDM_OK;                                   // (overlapped uploads: per-slot bookkeeping in ingest_images_impl)
+    return SDM_OK;  // the host reads h_act_count only after sync_counts*(): counts_queued() marks the read-backs of a call
+}
+// the list lengths of these slots have been requested (ingest_counts, possibly in several chunks): one event behind them
+int counts_queued(sdm_ctx* c, int n, const int* slots)
+{
+    const unsigned long long g = c->cnt_next++;
+    HIP_TRY(hipEventRecord(c->cnt_ev[g % sdm_ctx::CNT_RING], c->stream));
+    for (int i = 0; i < n; i++) c->slot_cnt[(size_t)slots[i]] = g;
+    return SDM_OK;
 }
 // the three launches of a chunk on the compute stream (+ k_ingest_batch for colour / distorted frames)
-int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q, hipStream_t ks = nullptr)
+int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q)
 {
-    if (!ks) ks = c->stream;
+    const hipStream_t ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     const int tiles_x = c->geom.tiles_x, ntiles = c->geom.ntiles;
     if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, *q);
@@ -376,8 +376,6 @@ int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams
     return SDM_OK;
 }
 
-int note_misc(sdm_ctx* c);
-
 // (re)build the active-pixel lists of `n` slots from their records for the current lambdaG (sdm_set_params changed it, or
 // the records came from the caller's own planes); the counts come back asynchronously
 int rebuild_lists(sdm_ctx* c, int n, const int* slots)
@@ -386,7 +384,7 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
     for (int i0 = 0; i0 < n; i0 += c->ing_cap) {
         const int m = std::min(c->ing_cap, n - i0);
         const int b = c->ing_next;
-        c->ing_next = (c->ing_next + 1) % sdm_ctx::ING_BUFS;
+        c->ing_next = (c->ing_next + 1) % c->ing_bufs;
         if ((rc = ingest_acquire(c, b, c->stream))) return rc;
         for (int i = 0; i < m; i++) {
             IngestItem& it = c->ing[b].h_items[i];
@@ -397,6 +395,7 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
         if ((rc = ingest_launch(c, b, m, false, nullptr))) return rc;
         if ((rc = ingest_counts(c, m, slots + i0))) return rc;
     }
+    if ((rc = counts_queued(c, n, slots))) return rc;
     for (int i = 0; i < n; i++) {
         const int slot = slots[i];
         if (c->act_lambdaG[slot] == c->act_lambdaG[slot]) {
@@ -408,42 +407,30 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
         c->act_lambdaG[slot] = c->dprm.lambdaG;
     }
     c->epoch++;
-    return note_misc(c);
+    return SDM_OK;
 }
 int build_active(sdm_ctx* c, int slot) { return rebuild_lists(c, 1, &slot); }
 
-// the host mirror of the list lengths is valid after this (uploads leave their read-backs in flight)
+// the host mirror of the list lengths is valid after this (uploads leave their read-backs in flight): every read-back ...
 int sync_counts(sdm_ctx* c)
 {
-    if (c->counts_pending) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->counts_pending = false;
-    }
-    if (c->cnt_done + 1 < c->cnt_next) {  // every overlapped upload's read-back (they complete in order on one stream)
-        HIP_TRY(hipStreamSynchronize(c->pre_stream));
+    if (c->cnt_done + 1 < c->cnt_next) {  // (they complete in order: one stream)
+        HIP_TRY(hipEventSynchronize(c->cnt_ev[(c->cnt_next - 1) % sdm_ctx::CNT_RING]));
         c->cnt_done = c->cnt_next - 1;
     }
     return SDM_OK;
 }
-// ... of these slots only (stage_tables): an overlapped upload that is still waiting for its turn behind an earlier step does
-// not hold up a compute call on OTHER slots
+// ... or the ones of these slots only (stage_tables): a compute call does not wait for the step that is executing to drain,
+// nor for a block that was uploaded behind it into other slots
 int sync_counts_for(sdm_ctx* c, int n_a, const int* a, size_t n_b, const int* b)
 {
-    if (c->counts_pending) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->counts_pending = false;
-    }
     unsigned long long g = 0;
     for (int i = 0; i < n_a; i++) g = std::max(g, c->slot_cnt[(size_t)a[i]]);
     for (size_t i = 0; i < n_b; i++) g = std::max(g, c->slot_cnt[(size_t)b[i]]);
     if (g > c->cnt_done) {
-        if (c->cnt_next - g >= (unsigned long long)sdm_ctx::CNT_RING) {  // its event was recycled: wait for all of them
-            HIP_TRY(hipStreamSynchronize(c->pre_stream));
-            c->cnt_done = c->cnt_next - 1;
-        } else {
-            HIP_TRY(hipEventSynchronize(c->cnt_ev[g % sdm_ctx::CNT_RING]));
-            c->cnt_done = g;
-        }
+        if (c->cnt_next - g >= (unsigned long long)sdm_ctx::CNT_RING) g = c->cnt_next - 1;  // its event was recycled: the newest
+        HIP_TRY(hipEventSynchronize(c->cnt_ev[g % sdm_ctx::CNT_RING]));
+        c->cnt_done = g;
     }
     return SDM_OK;
 }
@@ -575,7 +562,13 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
             for (size_t i = 0; i < (size_t)n_ref * (size_t)n; i++) look(nbr_slots[i]);
         if (!stale.empty() && (rc = rebuild_lists(c, (int)stale.size(), stale.data()))) return rc;
     }
+    static const bool dbg_st = getenv("SDM_DEBUG_STAGE_TIMING") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_s0 = dbg_st ? now_ms() : 0.0;
     if ((rc = sync_counts_for(c, n_ref, ref_slots, (size_t)n_ref * (size_t)n, nbr_slots))) return rc;  // grids follow h_act_count
+    if (dbg_st && now_ms() - t_s0 > 0.2)
+        fprintf(stderr, "[sdm stage] waited %.3f ms for list lengths (slot %d: read-back %llu, done %llu, next %llu)\n",
+                now_ms() - t_s0, ref_slots[0], c->slot_cnt[(size_t)ref_slots[0]], c->cnt_done, c->cnt_next);
 
     const size_t np = (size_t)n_ref * (size_t)n;
     auto matches = [&](const sdm_ctx::TableKey& k) {
@@ -611,7 +604,9 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     }
     const size_t words = select_set(c, victim, n_ref, np);
     c->table_stagings++;
+    const double t_w0 = dbg_st ? now_ms() : 0.0;
     if ((rc = wait_tables(c))) return rc;  // only if that set was staged within the last few calls
+    if (dbg_st && now_ms() - t_w0 > 0.2) fprintf(stderr, "[sdm stage] waited %.3f ms for table set %d\n", now_ms() - t_w0, victim);
     sdm_ctx::TableKey& k = c->sets[victim].key;
     k.valid = false;
     const size_t bytes = words * 4 + sizeof(long long) * 3 * (size_t)n_ref;
@@ -681,26 +676,9 @@ int stage_tables(sdm_ctx* c, int n_ref, const int* ref_slots, int n, const int* 
     return SDM_OK;
 }
 
-// an operation on the compute stream that writes slot data outside the table sets (see sdm_ctx::misc_last)
-int note_misc(sdm_ctx* c)
-{
-    if (!c->ingest_overlap) return SDM_OK;
-    const unsigned long long id = c->use_next++;
-    HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
-    c->misc_last = id;
-    return SDM_OK;
-}
-
-// end of a compute call (the staging block itself is released by the event recorded in stage_tables): with overlapped
-// ingest on, remember which slots the call used and mark its end on the compute stream
 int tables_staged(sdm_ctx* c)
 {
-    if (!c->ingest_overlap) return SDM_OK;
-    const sdm_ctx::TableKey& k = c->sets[c->cur_set].key;
-    const unsigned long long id = c->use_next++;
-    HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
-    for (int s_ : k.refs) c->slot_use[(size_t)s_] = id;
-    for (int s_ : k.nbrs) c->slot_use[(size_t)s_] = id;
+    (void)c;  // the staging block is released by the event recorded in stage_tables
     return SDM_OK;
 }
 
@@ -763,6 +741,23 @@ template <typename T>
 int host_alloc(T** p, size_t count)
 {
     HIP_TRY(hipHostMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1), hipHostMallocDefault));
+    return SDM_OK;
+}
+
+// chunk buffers [have, want) of the batched ingest (device image block, pinned staging ring, item tables, two events each)
+int alloc_ingest_bufs(sdm_ctx* c, int want)
+{
+    int rc;
+    for (int b = 0; b < want; b++) {
+        sdm_ctx::IngestBuf& B = c->ing[b];
+        if (B.d_img) continue;
+        if ((rc = dev_alloc(&B.d_img, (size_t)c->ing_cap * c->P)) || (rc = host_alloc(&B.h_ring, (size_t)c->ing_cap * c->P)) ||
+            (rc = dev_alloc(&B.d_items, (size_t)c->ing_cap)) || (rc = host_alloc(&B.h_items, (size_t)c->ing_cap)))
+            return rc;
+        if (hipEventCreateWithFlags(&B.copied, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&B.consumed, hipEventDisableTiming) != hipSuccess)
+            return fail(SDM_EHIP, "hipEventCreate failed");
+    }
     return SDM_OK;
 }
 
@@ -843,7 +838,6 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
     c->recon_lambdaG.assign(K, std::nanf(""));
     c->chk_sparse.assign(K, 1);  // planes start zeroed
     c->xyz_sparse.assign(K, 1);
-    c->slot_use.assign(K, 0);
     c->slot_cnt.assign(K, 0);
 
     int rc = SDM_OK;
@@ -909,31 +903,16 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
         c->ing_cap = (int)std::max<long long>(1, std::min<long long>(std::min(64, K), ((long long)32 << 20) / c->P));
         c->src_bytes = (size_t)std::max<long long>((long long)c->ing_cap * c->P, 4 * c->P);
         {
-            // the upload stream at the highest priority the device offers: its copies and the short pre-pass kernels run
-            // NEXT TO a step that fills the GPU (at equal priority they waited behind K1's 60 000 workgroups: measured)
+            // the upload stream (H2D copies of batch uploads) at the highest priority the device offers
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p) != hipSuccess ||
-                hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, hi_p) != hipSuccess)
+            if (hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi_p) != hipSuccess)
                 return bail(fail(SDM_EHIP, "hipStreamCreate failed"));
         }
-        if (hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming) != hipSuccess)
-            return bail(fail(SDM_EHIP, "hipEventCreate failed"));
         for (int i = 0; i < sdm_ctx::CNT_RING; i++)
             if (hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess)
                 return bail(fail(SDM_EHIP, "hipEventCreate failed"));
-        for (int i = 0; i < sdm_ctx::USE_RING; i++)
-            if (hipEventCreateWithFlags(&c->use_ev[i], hipEventDisableTiming) != hipSuccess)
-                return bail(fail(SDM_EHIP, "hipEventCreate failed"));
-        for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
-            sdm_ctx::IngestBuf& B = c->ing[b];
-            if ((rc = dev_alloc(&B.d_img, (size_t)c->ing_cap * c->P)) || (rc = host_alloc(&B.h_ring, (size_t)c->ing_cap * c->P)) ||
-                (rc = dev_alloc(&B.d_items, (size_t)c->ing_cap)) || (rc = host_alloc(&B.h_items, (size_t)c->ing_cap)))
-                return bail(rc);
-            if (hipEventCreateWithFlags(&B.copied, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&B.consumed, hipEventDisableTiming) != hipSuccess)
-                return bail(fail(SDM_EHIP, "hipEventCreate failed"));
-        }
+        if ((rc = alloc_ingest_bufs(c, c->ing_bufs))) return bail(rc);
         if ((rc = dev_alloc(&c->d_part, (size_t)c->ing_cap * c->geom.ntiles * PART_WORDS)) ||
             (rc = dev_alloc(&c->d_seg_mask, (size_t)c->ing_cap * c->nseg)) ||
             (rc = dev_alloc(&c->d_seg_off, (size_t)c->ing_cap * c->nseg)) || (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
@@ -1011,7 +990,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_grow_pix);
     (void)hipFree(c->d_grow_val);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
-    for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
+    for (int b = 0; b < sdm_ctx::ING_BUFS_MAX; b++) {
         sdm_ctx::IngestBuf& B = c->ing[b];
         (void)hipFree(B.d_img);
         (void)hipFree(B.d_src);
@@ -1023,15 +1002,8 @@ void sdm_destroy(sdm_ctx* c)
         if (B.consumed) (void)hipEventDestroy(B.consumed);
     }
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
-    if (c->pre_stream) {
-        (void)hipStreamSynchronize(c->pre_stream);
-        (void)hipStreamDestroy(c->pre_stream);
-    }
-    if (c->ev_ingest) (void)hipEventDestroy(c->ev_ingest);
     for (int i = 0; i < sdm_ctx::CNT_RING; i++)
         if (c->cnt_ev[i]) (void)hipEventDestroy(c->cnt_ev[i]);
-    for (int i = 0; i < sdm_ctx::USE_RING; i++)
-        if (c->use_ev[i]) (void)hipEventDestroy(c->use_ev[i]);
     (void)hipFree(c->d_part);
     (void)hipFree(c->d_seg_mask);
     (void)hipFree(c->d_seg_off);
@@ -1080,7 +1052,7 @@ int sdm_set_stream(sdm_ctx* c, void* s)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->counts_pending = false;  // everything queued on the old stream has finished
+    c->cnt_done = c->cnt_next - 1;  // everything queued on the old stream has finished
     if (c->own_stream) {
         (void)hipStreamDestroy(c->stream);
         c->own_stream = false;
@@ -1116,7 +1088,7 @@ int sdm_upload_keyframe(sdm_ctx* c, int slot, const uint8_t* im, const float* gr
     m.I_stddev = I_stddev;
     m.uploaded = 1;
     if ((rc = push_meta(c, slot, false))) return rc;
-    if ((rc = build_active(c, slot))) return rc;  // (ends with note_misc)
+    if ((rc = build_active(c, slot))) return rc;
     return sync_counts(c);  // the caller's (pageable) planes are released on return
 }
 
@@ -1238,9 +1210,10 @@ int check_batch_slots(sdm_ctx* c, int n, const int* slots)
 
 int ensure_src_buffers(sdm_ctx* c)
 {
-    if (c->ing[0].d_src) return SDM_OK;
+    if (c->ing[0].d_src && c->ing[c->ing_bufs - 1].d_src) return SDM_OK;
     int rc;
-    for (int b = 0; b < sdm_ctx::ING_BUFS; b++) {
+    for (int b = 0; b < c->ing_bufs; b++) {
+        if (c->ing[b].d_src) continue;
         if ((rc = dev_alloc(&c->ing[b].d_src, c->src_bytes))) return rc;
         if ((rc = host_alloc(&c->ing[b].h_src, c->src_bytes))) return rc;
     }
@@ -1285,24 +1258,6 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
     // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
     const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
-    // overlapped ingest (sdm_set_ingest_overlap): the kernels and the list-length read-back go to the upload stream as well,
-    // which first waits for the last compute call that used any of the target slots -- not for everything queued on the
-    // compute stream.  Not while an exchange is in flight (its transfers are ordered against the compute stream only) and not
-    // for images that live in device memory (whatever produced them is ordered against the compute stream only).
-    const bool overlap = c->ingest_overlap && n_chunks > 1 && !on_device && !c->xchg_pending && !c->ag_open;
-    const hipStream_t ks = overlap ? c->pre_stream : c->stream;
-    if (overlap) {
-        unsigned long long id = c->misc_last;
-        for (int i = 0; i < n; i++) id = std::max(id, c->slot_use[(size_t)slots[i]]);
-
-        if (id != 0) {
-            if (c->use_next - id >= (unsigned long long)sdm_ctx::USE_RING) {  // its event was recycled: wait for "now" instead
-                id = c->use_next++;
-                HIP_TRY(hipEventRecord(c->use_ev[id % sdm_ctx::USE_RING], c->stream));
-            }
-            HIP_TRY(hipStreamWaitEvent(c->pre_stream, c->use_ev[id % sdm_ctx::USE_RING], 0));
-        }
-    }
     double tdbg[6] = {0, 0, 0, 0, 0, 0};
     const double t_loop = dbg ? now() : 0.0;
     // An error in the middle of a batch: copies that read the caller's pinned images may still be in flight -- they are awaited
@@ -1324,7 +1279,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
         const int m = std::min(cap, n - i0);
         failed_from = i0;
         const int b = c->ing_next;
-        c->ing_next = (c->ing_next + 1) % sdm_ctx::ING_BUFS;
+        c->ing_next = (c->ing_next + 1) % c->ing_bufs;
         sdm_ctx::IngestBuf& B = c->ing[b];
         if (dbg) tdbg[0] = now();
         if ((rc = ingest_acquire(c, b, cs))) return bail(rc);
@@ -1361,7 +1316,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
             }
         }
         if (dbg) tdbg[2] = now();
-        if ((rc = ingest_publish(c, b, m, cs, ks))) return bail(rc);
+        if ((rc = ingest_publish(c, b, m, cs))) return bail(rc);
         if (dbg) tdbg[3] = now();
         for (int i = 0; i < m; i++) {
             const int slot = slots[i0 + i];
@@ -1369,9 +1324,9 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
             c->h_meta[slot] = B.h_items[i].meta;  // (I_stddev lives on the device only)
             c->act_lambdaG[slot] = c->dprm.lambdaG;
         }
-        if ((rc = ingest_launch(c, b, m, true, q, ks))) return bail(rc);
+        if ((rc = ingest_launch(c, b, m, true, q))) return bail(rc);
         if (dbg) tdbg[4] = now();
-        if ((rc = ingest_counts(c, m, slots + i0, ks))) return bail(rc);
+        if ((rc = ingest_counts(c, m, slots + i0))) return bail(rc);
         if (dbg) {
             tdbg[5] = now();
             if (tdbg[5] - tdbg[0] > dbg_ms)
@@ -1382,15 +1337,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     }
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
     // in place are awaited here (the pre-pass kernels are not)
-    if (overlap) {  // everything queued on the compute stream from here on sees the new keyframes
-        const unsigned long long g = c->cnt_next++;
-        HIP_TRY(hipEventRecord(c->cnt_ev[g % sdm_ctx::CNT_RING], c->pre_stream));  // (behind the last chunk's read-back)
-        for (int i = 0; i < n; i++) c->slot_cnt[(size_t)slots[i]] = g;
-        HIP_TRY(hipEventRecord(c->ev_ingest, c->pre_stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ingest, 0));
-    } else if ((rc = note_misc(c))) {
-        return rc;
-    }
+    if ((rc = counts_queued(c, n, slots))) return rc;  // one event behind the last chunk's read-back
     const double t_tail = dbg ? now() : 0.0;
     if (direct && last >= 0) {
         HIP_TRY(hipEventSynchronize(c->ing[last].copied));
@@ -1975,8 +1922,7 @@ int sdm_upload_depth(sdm_ctx* c, int slot, const float* rho, const float* sigma)
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->has_depth[slot] = 1;
     c->recon_lambdaG[slot] = std::nanf("");  // arbitrary map: support is no longer tied to the active list
-    if ((rc = upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma))) return rc;
-    return note_misc(c);
+    return upload_f2(c, c->pool + (long long)slot * c->P, rho, sigma);
 }
 
 int sdm_download_depth(sdm_ctx* c, int slot, float* rho, float* sigma)
@@ -2274,14 +2220,14 @@ int sdm_set_ingest_overlap(sdm_ctx* c, int on)
 {
     if (!c) return fail(SDM_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // a clean start: nothing in flight that the tracking has not seen
-    if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
-    if (c->pre_stream) HIP_TRY(hipStreamSynchronize(c->pre_stream));
-    c->counts_pending = false;
-    c->cnt_done = c->cnt_next - 1;
-    c->ingest_overlap = on != 0;
-    std::fill(c->slot_use.begin(), c->slot_use.end(), 0ull);
-    c->misc_last = 0;
+    if (on && c->ing_bufs < sdm_ctx::ING_BUFS_MAX) {  // three 64-keyframe blocks' worth of chunk buffers
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
+        const int rc = alloc_ingest_bufs(c, sdm_ctx::ING_BUFS_MAX);
+        if (rc) return rc;
+        c->ing_bufs = sdm_ctx::ING_BUFS_MAX;
+    }
+    c->ingest_overlap = on != 0;  // (switching it off keeps the buffers: they are in the ring's rotation)
     return SDM_OK;
 }
 

@@ -44,12 +44,14 @@ class Model:
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("SDM_FUZZ_FIRST", "1")), int(os.environ.get("SDM_FUZZ_FIRST", "1")) +
                                              int(os.environ.get("SDM_FUZZ_SEEDS", "8")))))  # env: deeper one-off runs
-def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_random_call_sequences(pkg, oracle, gpu_ok, seed, overlap):
     rng = np.random.default_rng(7000 + seed)
     W, H, n_kf, n = 96, 72, 8, 5
     seq = Sequence(pkg, oracle, W, H, n_kf, 0x5EED0F00 + seed)  # consistent geometry: the checks keep many pixels
     K = seq.K
     eng = pkg.Engine(W, H, n_kf, max_neighbours=n, with_pointset=True)
+    eng.set_ingest_overlap(overlap)  # batch uploads of >= 5 keyframes then run next to whatever does not use their slots
     m = Model(oracle, W, H, n_kf, K)
     lam = 8.0
     oracle.params.lambdaG = lam
@@ -67,9 +69,32 @@ def test_random_call_sequences(pkg, oracle, gpu_ok, seed):
                 nbrs = [[int(j) for j in rng.permutation([j for j in range(n_kf) if j != k])[:n]] for k in refs]
             op = rng.choice(["recon"] * 6 + ["fused"] * 4 + ["inter"] * 3 + ["inter_commit", "search_fuse", "intra_check",
                              "intra_grow", "pointset0", "pointset1", "pointset1", "upload_depth", "assume", "set_pose",
-                             "lambda", "lambda", "reupload"])
+                             "lambda", "lambda", "reupload", "recon+batch"])
             touched = list(refs)
-            if op == "recon":
+            if op in ("recon+batch", "batch"):
+                # a reconstruction is queued and, without waiting for it, a batch of 5 .. 8 keyframes (other images: the
+                # neighbour's) is uploaded into slots that may be the ones it reads or writes: the engine must order them
+                if op == "recon+batch":
+                    eng.recon(refs, nbrs, mind, maxd)
+                    for k, nb in zip(refs, nbrs):
+                        m.rho[k], m.sig[k], _ = oracle.semi_dense_recon(m.kf(k), [m.kf(j) for j in nb], None, mind, maxd)
+                        m.has_depth[k] = True
+                bs = sorted(rng.choice(n_kf, int(rng.integers(5, n_kf + 1)), replace=False).tolist())
+                # (the same views a little brighter or darker: new records, lists and maps, the geometry stays consistent)
+                d = int(rng.integers(-3, 4))
+                ims = [np.clip(seq.im[k].astype(np.int32) + d, 0, 255).astype(np.uint8) for k in bs]
+                eng.upload_images_batch(bs, ims, K, [seq.Tcw[k] for k in bs])
+                for k, im in zip(bs, ims):
+                    m.upload_image(k, im, seq.Tcw[k])
+                # ... and the new keyframes are reconstructed at once (queued behind the upload; keeps the sequence's
+                # inter-keyframe checks alive: a fresh keyframe has no depth map)
+                bn = [seq.neighbours(k, n) for k in bs]
+                eng.recon(bs, bn, mind, maxd)
+                for k, nb in zip(bs, bn):
+                    m.rho[k], m.sig[k], _ = oracle.semi_dense_recon(m.kf(k), [m.kf(j) for j in nb], None, mind, maxd)
+                    m.has_depth[k] = True
+                touched = sorted(set(refs if op == "recon+batch" else []) | set(bs))
+            elif op == "recon":
                 eng.recon(refs, nbrs, mind, maxd)
                 for k, nb in zip(refs, nbrs):
                     m.rho[k], m.sig[k], _ = oracle.semi_dense_recon(m.kf(k), [m.kf(j) for j in nb], None, mind, maxd)

@@ -20,28 +20,28 @@ n_slots = pl["n_slots"]
 ims = [wl.images[k] for k in ks]
 poses = [wl.scene.Tcw(k) for k in ks]
 gc.disable()
+AHEAD = int(os.environ.get("AHEAD", "3"))
 for overlap in (False, True):
-    eng = pkg.Engine(wl.W, wl.H, 2 * n_slots, max_neighbours=wl.N, batch_capacity=64, with_pointset=True)
+    eng = pkg.Engine(wl.W, wl.H, AHEAD * n_slots, max_neighbours=wl.N, batch_capacity=64, with_pointset=True)
     eng.set_ingest_overlap(overlap)
     shift = lambda lst, off: [s_ + off for s_ in lst]
-    pls = [dict(pl, own_slots=shift(pl["own_slots"], h * n_slots), nbr_slots=[shift(r, h * n_slots) for r in pl["nbr_slots"]]) for h in (0, 1)]
-    slots = [[pl["slot"][k] + h * n_slots for k in ks] for h in (0, 1)]
+    pls = [dict(pl, own_slots=shift(pl["own_slots"], h * n_slots), nbr_slots=[shift(r, h * n_slots) for r in pl["nbr_slots"]]) for h in range(AHEAD)]
+    slots = [[pl["slot"][k] + h * n_slots for k in ks] for h in range(AHEAD)]
     step = lambda h: pkg.shard.pipeline_step(eng, None, pls[h], wl.min_d, wl.max_d, "none", None, "torch")
     for _ in range(3):
-        eng.upload_images_batch(slots[1], ims, wl.K, poses); step(1)
-        eng.upload_images_batch(slots[0], ims, wl.K, poses); step(0)
+        for h in range(AHEAD):
+            eng.upload_images_batch(slots[h], ims, wl.K, poses); step(h)
     eng.synchronize()
     ts, tu = [], []
     t0 = time.perf_counter()
     eng.upload_images_batch(slots[0], ims, wl.K, poses)
-    eng.upload_images_batch(slots[1], ims, wl.K, poses)
     for i in range(20):
         a = time.perf_counter()
-        step(i & 1)
+        eng.upload_images_batch(slots[(i + 1) % AHEAD], ims, wl.K, poses)  # the next block first ...
         b = time.perf_counter()
-        eng.upload_images_batch(slots[i & 1], ims, wl.K, poses)  # two blocks ahead, into the half being stepped
+        step(i % AHEAD)                                                     # ... then this one's step
         c = time.perf_counter()
-        ts.append(b - a); tu.append(c - b)
+        tu.append(b - a); ts.append(c - b)
     eng.synchronize()
     dt = time.perf_counter() - t0
     # the pieces on their own
