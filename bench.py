@@ -700,7 +700,7 @@ def main():
         dist.destroy_process_group()
 
 
-def streaming_rate(pkg, torch, wl, iters=12, pinned=False):
+def streaming_rate(pkg, torch, wl, iters=40, pinned=False):
     """Sustained ingest + compute (frames arrive continuously in the fork: src/Tracking.cc:266-271 -> Modeler.cc:1496-1514):
     the block's keyframes arrive as host gray images every iteration -- sdm_upload_images_batch into the other half of a
     double-sized slot pool, issued BEFORE the current block's step is queued: with the streaming ingest on

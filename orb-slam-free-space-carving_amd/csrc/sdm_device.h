@@ -97,17 +97,14 @@ __host__ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     const float p3 = -0.3258083974640975f * scale;
     const float p5 = 0.1555786518463281f * scale;
     const float p7 = -0.04432655554792128f * scale;
-    float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    const float ax = fabsf(x), ay = fabsf(y);
+    // the two branches of atan_f32 differ in which magnitude is divided by which and in the final 90 - p: one quotient and
+    // one polynomial on selected operands (the same operations on the same values as either branch)
+    const bool flat = ax >= ay;
+    const float c = (flat ? ay : ax) / ((flat ? ax : ay) + (float)DBL_EPSILON);
+    const float c2 = c * c;
+    const float p = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = flat ? p : 90.f - p;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;

@@ -109,6 +109,7 @@ struct sdm_ctx {
         hipEvent_t copied = nullptr;    // this chunk's H2D copies (upload stream) have finished
         hipEvent_t consumed = nullptr;  // the kernels that read d_img / d_src / d_items (compute stream) have finished
         bool copied_pending = false, consumed_pending = false;
+        int consumed_from = -1;         // >= 0: the `consumed` event of THAT buffer covers this one too (one record per merged launch)
     } ing[12];
     static constexpr int ING_BUFS_MAX = 12;
     int ing_bufs = 4;  // in use: four (a 64-keyframe block goes through in four chunks without a copy waiting for an earlier
@@ -116,9 +117,13 @@ struct sdm_ctx {
     int ing_next = 0;
     size_t src_bytes = 0;
     hipStream_t up_stream = nullptr;
-    unsigned long long* d_part = nullptr;      // [ing_cap][ntiles][PART_WORDS] per-tile partial sums
-    unsigned long long* d_seg_mask = nullptr;  // [ing_cap][nseg] lambdaG-gate lane mask of every 64-pixel row segment
-    int* d_seg_off = nullptr;                  // [ing_cap][nseg] list offset of every row segment
+    // per GROUP of up to ING_GROUP chunks: the chunks' first kernels fill these, k_prepass_finish / k_list_write run once per group
+    static constexpr int ING_GROUP = 4;
+    static_assert(ING_GROUP == CHUNK_TABLES, "one merged launch covers a group");
+    unsigned long long* d_part = nullptr;      // [ING_GROUP * ing_cap][ntiles][PART_WORDS] per-tile partial sums
+    unsigned long long* d_seg_mask = nullptr;  // [ING_GROUP * ing_cap][nseg] lambdaG-gate lane mask of every 64-pixel row segment
+    int* d_seg_off = nullptr;                  // [ING_GROUP * ing_cap][nseg] list offset of every row segment
+    IngestItem* d_gitems = nullptr;            // [ING_GROUP * ing_cap] the group's keyframes (copied from the chunks' tables)
     int nseg = 0;                              // H * tiles_x
     unsigned long long* d_act_hash = nullptr;  // [max_keyframes] hash of the active-pixel set (compact wire header)
     unsigned* d_gmask = nullptr;               // [max_keyframes][H][mrow][MASK_PLANES] gate bit planes of every slot, one dword
@@ -311,39 +316,27 @@ int ingest_acquire(sdm_ctx* c, int b, hipStream_t copy_stream)
         B.copied_pending = false;
     }
     if (B.consumed_pending) {
-        HIP_TRY(hipStreamWaitEvent(copy_stream, B.consumed, 0));  // (the kernels may have run on either stream)
+        // (the buffers are reused in ring order, so a group's last buffer has not been recorded again when an earlier one is
+        // acquired; if it had been, this would wait for later work, never for less)
+        HIP_TRY(hipStreamWaitEvent(copy_stream, B.consumed_from >= 0 ? c->ing[B.consumed_from].consumed : B.consumed, 0));
         B.consumed_pending = false;
     }
     return SDM_OK;
 }
 // the chunk's item table goes up behind whatever image copies were queued on the upload stream; the compute stream waits
 // for all of it
-int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream)
+int ingest_publish(sdm_ctx* c, int b, int m, hipStream_t copy_stream, bool compute_waits = true)
 {
     const hipStream_t ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     HIP_TRY(hipMemcpyAsync(B.d_items, B.h_items, sizeof(IngestItem) * (size_t)m, hipMemcpyHostToDevice, copy_stream));
     HIP_TRY(hipEventRecord(B.copied, copy_stream));
     B.copied_pending = true;
-    if (copy_stream != ks) HIP_TRY(hipStreamWaitEvent(ks, B.copied, 0));
+    if (copy_stream != ks && compute_waits) HIP_TRY(hipStreamWaitEvent(ks, B.copied, 0));
     return SDM_OK;
 }
-// list lengths of the chunk's slots -> pinned host mirror (one copy when the slots are consecutive)
-int ingest_counts(sdm_ctx* c, int m, const int* slots)
-{
-    bool run = true;
-    for (int i = 1; i < m; i++) run = run && slots[i] == slots[0] + i;
-    if (run) {
-        HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[0]], c->d_act_count + slots[0], sizeof(int) * (size_t)m,
-                               hipMemcpyDeviceToHost, c->stream));
-    } else {
-        for (int i = 0; i < m; i++)
-            HIP_TRY(hipMemcpyAsync(&c->h_act_count[slots[i]], c->d_act_count + slots[i], sizeof(int), hipMemcpyDeviceToHost,
-                                   c->stream));
-    }
-    return SDM_OK;  // the host reads h_act_count only after sync_counts*(): counts_queued() marks the read-backs of a call
-}
-// the list lengths of these slots have been requested (ingest_counts, possibly in several chunks): one event behind them
+// the list lengths of these slots are on their way (k_prepass_finish stores them into the pinned host mirror): one event behind
+// the kernels queued so far; the host reads h_act_count only after sync_counts*()
 int counts_queued(sdm_ctx* c, int n, const int* slots)
 {
     const unsigned long long g = c->cnt_next++;
@@ -351,28 +344,68 @@ int counts_queued(sdm_ctx* c, int n, const int* slots)
     for (int i = 0; i < n; i++) c->slot_cnt[(size_t)slots[i]] = g;
     return SDM_OK;
 }
-// the three launches of a chunk on the compute stream (+ k_ingest_batch for colour / distorted frames)
-int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams* q)
+// a chunk's first kernel(s) on the compute stream: its m keyframes are numbers kf0 .. kf0 + m - 1 of their group
+int ingest_launch_chunk(sdm_ctx* c, int b, int m, int kf0, bool from_images, const IngestParams* q)
 {
     const hipStream_t ks = c->stream;
     sdm_ctx::IngestBuf& B = c->ing[b];
     const int tiles_x = c->geom.tiles_x, ntiles = c->geom.ntiles;
+    if (kf0 < 0 || kf0 + m > sdm_ctx::ING_GROUP * c->ing_cap) return fail(SDM_EINVAL, "ingest group overflow (internal)");
     if (q) hipLaunchKernelGGL(k_ingest_batch, dim3(blocks_for(c->P), m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, *q);
-    if (from_images)
-        hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, tiles_x, c->P,
-                           c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask,
-                           c->mrow);
-    else
+    if (from_images) {
+        ChunkTables tabs;
+        for (int i = 0; i < CHUNK_TABLES; i++) tabs.p[i] = B.d_items;
+        tabs.per = std::max(m, 1);
+        hipLaunchKernelGGL(k_prepass_batch<true>, dim3(ntiles, m), dim3(BLOCK), 0, ks, tabs, c->W, c->H, tiles_x, c->P, c->rec,
+                           c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask, c->mrow, kf0,
+                           c->d_gitems);
+    } else {
         hipLaunchKernelGGL(k_gate_batch, dim3(ntiles, m), dim3(BLOCK), 0, ks, B.d_items, c->W, c->H, tiles_x, c->P, c->rec,
-                           c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask, c->mrow);
-    hipLaunchKernelGGL(k_prepass_finish, dim3(m), dim3(FIN_BLOCK), 0, ks, B.d_items, c->W, c->H, ntiles, c->nseg, c->d_part,
-                       c->d_seg_mask, c->d_seg_off, c->d_meta, c->d_act_count, c->d_theta_bad, c->d_act_hash,
-                       from_images ? 1 : 0);
-    hipLaunchKernelGGL(k_list_write, dim3((c->nseg + BLOCK / 64 - 1) / (BLOCK / 64), m), dim3(BLOCK), 0, ks, B.d_items,
-                       tiles_x, c->nseg, c->P, c->d_seg_mask, c->d_seg_off, c->d_act);
+                           c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask, c->mrow, kf0, c->d_gitems);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(B.consumed, ks));
     B.consumed_pending = true;
+    B.consumed_from = -1;
+    return SDM_OK;
+}
+// the same for the chunks of a whole group in ONE launch (gray images whose copies were queued on the upload stream and are
+// not awaited chunk by chunk: the streaming ingest): chunk i lies in buffer bufs[i] and holds `per` keyframes, the last one
+// total - (n_chunks - 1) * per
+int ingest_launch_chunks_merged(sdm_ctx* c, int n_chunks, const int* bufs, int per, int total)
+{
+    const hipStream_t ks = c->stream;
+    if (n_chunks < 1 || n_chunks > CHUNK_TABLES || total > sdm_ctx::ING_GROUP * c->ing_cap || per < 1 ||
+        total <= (n_chunks - 1) * per || total > n_chunks * per)
+        return fail(SDM_EINVAL, "merged ingest launch: bad chunk shape (internal)");
+    ChunkTables tabs;
+    for (int i = 0; i < CHUNK_TABLES; i++) tabs.p[i] = c->ing[bufs[std::min(i, n_chunks - 1)]].d_items;
+    tabs.per = per;
+    HIP_TRY(hipStreamWaitEvent(ks, c->ing[bufs[n_chunks - 1]].copied, 0));  // (the upload stream copies in order)
+    hipLaunchKernelGGL(k_prepass_batch<true>, dim3(c->geom.ntiles, total), dim3(BLOCK), 0, ks, tabs, c->W, c->H, c->geom.tiles_x,
+                       c->P, c->rec, c->pool, c->chk, c->xyz, c->dprm.lambdaG, c->d_part, c->d_seg_mask, c->nseg, c->d_gmask,
+                       c->mrow, 0, c->d_gitems);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ing[bufs[n_chunks - 1]].consumed, ks));
+    for (int i = 0; i < n_chunks; i++) {
+        c->ing[bufs[i]].consumed_pending = true;
+        c->ing[bufs[i]].consumed_from = i == n_chunks - 1 ? -1 : bufs[n_chunks - 1];
+    }
+    return SDM_OK;
+}
+// ... and the two launches that finish a group of chunks (n_kf keyframes): list offsets, lengths (device table and the host's
+// pinned mirror), hashes, metadata; then the lists
+int ingest_launch_group(sdm_ctx* c, int n_kf, bool from_images)
+{
+    if (n_kf <= 0) return SDM_OK;
+    const hipStream_t ks = c->stream;
+    hipLaunchKernelGGL(k_prepass_finish, dim3(n_kf), dim3(FIN_BLOCK), 0, ks, c->d_gitems, c->W, c->H, c->geom.ntiles, c->nseg,
+                       c->d_part, c->d_seg_mask, c->d_seg_off, c->d_meta, c->d_act_count, c->h_act_count, c->d_theta_bad,
+                       c->d_act_hash, from_images ? 1 : 0);
+    const int waves = (c->nseg + LIST_SEGS - 1) / LIST_SEGS;
+    hipLaunchKernelGGL(k_list_write, dim3((waves + BLOCK / 64 - 1) / (BLOCK / 64), n_kf), dim3(BLOCK), 0, ks, c->d_gitems,
+                       c->geom.tiles_x, c->nseg, c->P, c->d_seg_mask, c->d_seg_off, c->d_act);
+    HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
 
@@ -381,6 +414,7 @@ int ingest_launch(sdm_ctx* c, int b, int m, bool from_images, const IngestParams
 int rebuild_lists(sdm_ctx* c, int n, const int* slots)
 {
     int rc;
+    int group_kfs = 0, group_chunks = 0;
     for (int i0 = 0; i0 < n; i0 += c->ing_cap) {
         const int m = std::min(c->ing_cap, n - i0);
         const int b = c->ing_next;
@@ -392,8 +426,12 @@ int rebuild_lists(sdm_ctx* c, int n, const int* slots)
             it.slot = slots[i0 + i];
         }
         if ((rc = ingest_publish(c, b, m, c->stream))) return rc;
-        if ((rc = ingest_launch(c, b, m, false, nullptr))) return rc;
-        if ((rc = ingest_counts(c, m, slots + i0))) return rc;
+        if ((rc = ingest_launch_chunk(c, b, m, group_kfs, false, nullptr))) return rc;
+        group_kfs += m;
+        if (++group_chunks == sdm_ctx::ING_GROUP || i0 + m >= n) {
+            if ((rc = ingest_launch_group(c, group_kfs, false))) return rc;
+            group_kfs = group_chunks = 0;
+        }
     }
     if ((rc = counts_queued(c, n, slots))) return rc;
     for (int i = 0; i < n; i++) {
@@ -913,9 +951,10 @@ int sdm_create(sdm_ctx** out, const sdm_config* cfg)
             if (hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess)
                 return bail(fail(SDM_EHIP, "hipEventCreate failed"));
         if ((rc = alloc_ingest_bufs(c, c->ing_bufs))) return bail(rc);
-        if ((rc = dev_alloc(&c->d_part, (size_t)c->ing_cap * c->geom.ntiles * PART_WORDS)) ||
-            (rc = dev_alloc(&c->d_seg_mask, (size_t)c->ing_cap * c->nseg)) ||
-            (rc = dev_alloc(&c->d_seg_off, (size_t)c->ing_cap * c->nseg)) || (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
+        const size_t gcap = (size_t)sdm_ctx::ING_GROUP * c->ing_cap;
+        if ((rc = dev_alloc(&c->d_part, gcap * c->geom.ntiles * PART_WORDS)) || (rc = dev_alloc(&c->d_seg_mask, gcap * c->nseg)) ||
+            (rc = dev_alloc(&c->d_seg_off, gcap * c->nseg)) || (rc = dev_alloc(&c->d_gitems, gcap)) ||
+            (rc = dev_alloc(&c->d_act_hash, (size_t)K)))
             return bail(rc);
         c->mrow = 2 * (c->geom.tiles_x + 1);
         if ((rc = dev_alloc(&c->d_gmask, (size_t)K * c->H * MASK_PLANES * c->mrow))) return bail(rc);
@@ -1007,6 +1046,7 @@ void sdm_destroy(sdm_ctx* c)
     (void)hipFree(c->d_part);
     (void)hipFree(c->d_seg_mask);
     (void)hipFree(c->d_seg_off);
+    (void)hipFree(c->d_gitems);
     (void)hipFree(c->d_act_hash);
     (void)hipFree(c->d_gmask);
     (void)hipFree(c->d_im);
@@ -1258,16 +1298,33 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
     // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
     const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
-    double tdbg[6] = {0, 0, 0, 0, 0, 0};
+    double tdbg[5] = {0, 0, 0, 0, 0};
     const double t_loop = dbg ? now() : 0.0;
     // An error in the middle of a batch: copies that read the caller's pinned images may still be in flight -- they are awaited
     // before the call returns (the promise "every caller buffer is free on return" holds on the error path too).  Slots of
     // chunks that were already launched hold their new keyframes; the slots of the failing and the later chunks are reset
     // (no keyframe): the call reports failure for the batch, sdm_upload_* can simply be repeated.
     int failed_from = n;
+    int group_kfs = 0, group_chunks = 0;  // chunks whose first kernels are queued and whose group is not finished yet
+    int group_first = 0;                  // index of that group's first keyframe
+    // streaming ingest: the copies run ahead of the compute stream anyway, so the chunks of a group share ONE pre-pass launch
+    // behind ONE wait for the group's last copy (per-chunk launches start the first chunk's kernel a copy earlier, which only
+    // matters when the compute stream has nothing else to do)
+    const bool merge = c->ingest_overlap && n_chunks > 1 && !q && !on_device && cs != c->stream;
+    int merged_bufs[CHUNK_TABLES] = {0, 0, 0, 0};
+    auto finish_group = [&]() -> int {
+        const int g = group_kfs, nch = group_chunks;
+        group_kfs = group_chunks = 0;
+        int r = SDM_OK;
+        if (merge && nch > 0) r = ingest_launch_chunks_merged(c, nch, merged_bufs, cap, g);
+        if (!r) r = ingest_launch_group(c, g, true);
+        return r;
+    };
     auto bail = [&](int code) {
         const std::string keep = g_err;
         if (direct) (void)hipStreamSynchronize(cs);
+        (void)finish_group();  // the chunks before the failing one keep their keyframes
+        (void)counts_queued(c, failed_from, slots);
         for (int i = failed_from; i < n; i++) {
             reset_slot_state(c, slots[i]);
             c->h_meta[slots[i]].uploaded = 0;
@@ -1316,22 +1373,34 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
             }
         }
         if (dbg) tdbg[2] = now();
-        if ((rc = ingest_publish(c, b, m, cs))) return bail(rc);
+        if ((rc = ingest_publish(c, b, m, cs, !merge))) return bail(rc);
         if (dbg) tdbg[3] = now();
         for (int i = 0; i < m; i++) {
             const int slot = slots[i0 + i];
             reset_slot_state(c, slot);
             c->h_meta[slot] = B.h_items[i].meta;  // (I_stddev lives on the device only)
             c->act_lambdaG[slot] = c->dprm.lambdaG;
+            c->recon_lambdaG[slot] = c->dprm.lambdaG;  // k_prepass_batch<ZERO> leaves an all-zero map: K1 need not clear it again
         }
-        if ((rc = ingest_launch(c, b, m, true, q))) return bail(rc);
-        if (dbg) tdbg[4] = now();
-        if ((rc = ingest_counts(c, m, slots + i0))) return bail(rc);
+        if (merge)
+            merged_bufs[group_chunks] = b;
+        else if ((rc = ingest_launch_chunk(c, b, m, group_kfs, true, q)))
+            return bail(rc);
+        group_kfs += m;
+        group_chunks++;
+        failed_from = i0 + m;
+        if (group_chunks == sdm_ctx::ING_GROUP || i0 + m >= n) {
+            if ((rc = finish_group())) {
+                failed_from = group_first;  // no lists for any keyframe of this group
+                return bail(rc);
+            }
+            group_first = i0 + m;
+        }
         if (dbg) {
-            tdbg[5] = now();
-            if (tdbg[5] - tdbg[0] > dbg_ms)
-                fprintf(stderr, "[sdm ingest] slow chunk: acquire %.3f  images %.3f  publish %.3f  launch %.3f  counts %.3f ms\n",
-                        tdbg[1] - tdbg[0], tdbg[2] - tdbg[1], tdbg[3] - tdbg[2], tdbg[4] - tdbg[3], tdbg[5] - tdbg[4]);
+            tdbg[4] = now();
+            if (tdbg[4] - tdbg[0] > dbg_ms)
+                fprintf(stderr, "[sdm ingest] slow chunk: acquire %.3f  images %.3f  publish %.3f  launch %.3f ms\n",
+                        tdbg[1] - tdbg[0], tdbg[2] - tdbg[1], tdbg[3] - tdbg[2], tdbg[4] - tdbg[3]);
         }
         last = b;
     }

@@ -31,6 +31,18 @@ struct IngestItem {      // one keyframe of an ingest batch (device table, stage
     int keep_istd;       // k_prepass_finish leaves the slot's I_stddev alone
     KfMeta meta;         // stored into the slot's metadata (I_stddev is filled in on the device)
 };
+// the item tables of the chunks one k_prepass_batch launch covers: keyframe kf of the launch = p[kf / per][kf % per]
+// (one chunk: p[0] and per >= its size; several chunks in one launch: all but the last hold `per` keyframes)
+constexpr int CHUNK_TABLES = 4;
+struct ChunkTables {
+    const IngestItem* p[CHUNK_TABLES];
+    int per;
+};
+__device__ __forceinline__ const IngestItem& chunk_item(const ChunkTables& t, int kf)
+{
+    const int ch = kf / t.per;
+    return t.p[ch][kf - ch * t.per];
+}
 
 // ---- K(-1): image ingest -- what the fork does to a camera frame before the path sees it --------------------
 // src/Tracking.cc:266-271 undistorts the (colour) frame with cv::undistort(im, imu, mK, mDistCoef) and hands it to
@@ -111,12 +123,16 @@ __device__ __forceinline__ bool act_gate(float grad, int x, int y, int W, int H,
     return (x >= 2 && x < W - 2 && y >= 2 && y < H - 2) &&  // PM.cc:198-199
            !(grad < lambdaG);                                // PM.cc:201
 }
-// Hash of the gated pixel SET (the list is that set in raster order, so equal sets <=> equal lists): the sum over its
-// pixels of a 64-bit mix of (y << 16 | x).  Sender and receiver of a compact map compare length and hash (sdm_comm.h).
-__device__ __forceinline__ unsigned long long list_hash_term(unsigned xy)
+// Hash of the gated pixel SET (the list is that set in raster order, so equal sets <=> equal lists <=> equal gate masks of all
+// 64-pixel row segments): the sum over the row segments with a non-empty mask of a 64-bit mix of the mask and the segment's
+// first pixel (y << 16 | x0).  One term per wave and row, from a ballot -- wave-uniform, so it is scalar-unit work (a term per
+// PIXEL, the rounds 2-4 definition, was a fifth of the pre-pass's vector instructions: two 64-bit multiplies per lane).
+// Sender and receiver of a compact map compare length and hash (sdm_comm.h); shard.list_hash is the numpy statement.
+__device__ __forceinline__ unsigned long long seg_hash_term(unsigned long long mask, unsigned y, unsigned x0)
 {
-    unsigned long long z = (unsigned long long)xy + 0x9E3779B97F4A7C15ull;  // SplitMix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    if (mask == 0ull) return 0ull;
+    unsigned long long z = mask ^ ((unsigned long long)((y << 16) | x0) * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;  // SplitMix64 finaliser
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
@@ -125,15 +141,45 @@ constexpr int PART_WORDS = 4;  // per-tile partials: sum of im, sum of im^2, lis
 constexpr int PRE_HALO_W = TILE_W + 2;
 constexpr int PRE_HALO_H = TILE_H + 3;  // the record of row y also holds GradImg(y+1): one more gradient row per tile
 
-__device__ __forceinline__ void block_sum4(unsigned long long (&v)[PART_WORDS], unsigned long long* red /* [4][BLOCK/64] */)
+// a tile's partials -> part_tile[PART_WORDS]: s1, s2 = the thread's sums of im and im^2 (32 bits hold a tile's: 1024 * 255^2),
+// hsum / bad = the WAVE's hash terms and flag (uniform)
+__device__ __forceinline__ void tile_partials(unsigned s1, unsigned s2, unsigned long long hsum, bool bad,
+                                              unsigned long long* red /* [PART_WORDS][BLOCK/64] */,
+                                              unsigned long long* __restrict__ part_tile)
 {
-#pragma unroll
-    for (int k = 0; k < PART_WORDS; k++)
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int k = 0; k < PART_WORDS; k++) red[k * (BLOCK / 64) + (threadIdx.x >> 6)] = v[k];
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+    }
+    const int wv = (int)(threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) {
+        red[0 * (BLOCK / 64) + wv] = s1;
+        red[1 * (BLOCK / 64) + wv] = s2;
+        red[2 * (BLOCK / 64) + wv] = hsum;
+        red[3 * (BLOCK / 64) + wv] = bad ? 1ull : 0ull;
+    }
     __syncthreads();
+    if (threadIdx.x < PART_WORDS) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < BLOCK / 64; w++) tot += red[threadIdx.x * (BLOCK / 64) + w];
+        part_tile[threadIdx.x] = tot;
+    }
+}
+
+// sqrtf(x) for x = (sx^2 + sy^2) / 1024 with integers |sx|, |sy| <= 16 * 255: x is 0 or lies in [2^-10, 2^15), where
+// x * rsq(x) plus one residual step is the IEEE square root bit for bit (sdm_device.h sqrt_exact: exhaustive over
+// [2^-102, 2^128), profiles/r04_exact_ops.txt); 0 is selected, not branched on
+__device__ __forceinline__ float sqrt_grad(float x)
+{
+#if SDM_K1_OPT & 0x10000
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float y0 = x * r, h = 0.5f * r;
+    const float e = __builtin_fmaf(-y0, y0, x);
+    const float y = __builtin_fmaf(e, h, y0);
+    return x == 0.0f ? 0.0f : y;
+#else
+    return sqrtf(x);
+#endif
 }
 
 // Scharr/32 gradient at tile pixel (lx, ly) from the staged image tile (3x3 neighbourhood rows ly..ly+2, columns
@@ -158,18 +204,24 @@ __device__ __forceinline__ void scharr32(const uint8_t (*t)[PRE_HALO_W], int lx,
 __device__ __forceinline__ void write_gate_planes(unsigned* __restrict__ gmask, long long row_dword0, int tx, bool sgate, float theta,
                                                   bool store)
 {
+    // six ballots -- the gate, "gated with an angle in [0,360)", the four bits of the bin -- instead of one per plane: lane p
+    // assembles plane p's word from them with its own constants (k-th bit of its bin set ? B_k : ~B_k)
     const bool in_range = (theta >= 0.0f) & (theta < 360.0f);
-    const int bin = in_range ? mask_bin(theta) : -1;
+    const int bin = in_range ? mask_bin(theta) : 0;
     const int lane = (int)(threadIdx.x & 63u);
     const int mybin = lane < MASK_BINS ? lane : lane - MASK_BINS;
-    unsigned long long mine = 0ull;
+    static_assert(MASK_BINS == 16, "four bin bits");
+    const unsigned long long G = __builtin_amdgcn_ballot_w64(sgate);
+    const unsigned long long R = __builtin_amdgcn_ballot_w64(sgate & in_range);
+    unsigned long long mine = R;
 #pragma unroll
-    for (int b = 0; b < MASK_BINS; b++) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(sgate & ((bin == b) | !in_range));
-        if (mybin == b) mine = m;
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long Bk = __builtin_amdgcn_ballot_w64((bin >> k) & 1);
+        const unsigned long long flip = ((mybin >> k) & 1) ? 0ull : ~0ull;
+        mine &= Bk ^ flip;
     }
-    const unsigned long long all = __builtin_amdgcn_ballot_w64(sgate);
-    if (lane == MASK_UNION) mine = all;
+    mine |= G & ~R;  // an angle outside [0,360) belongs to every bin
+    if (lane == MASK_UNION) mine = G;
     if (store && lane < MASK_PLANES) {
         gmask[row_dword0 + (long long)(2 * tx) * MASK_PLANES + lane] = (unsigned)mine;
         gmask[row_dword0 + (long long)(2 * tx + 1) * MASK_PLANES + lane] = (unsigned)(mine >> 32);
@@ -179,31 +231,37 @@ __device__ __forceinline__ void write_gate_planes(unsigned* __restrict__ gmask, 
 // grid (tiles, keyframes).  ZERO: the slot receives a new keyframe -- its depth map, checked plane and point set start
 // as zeros (a fresh KeyFrame's depth_map_ / depth_sigma_ / SemiDensePointSets_)
 template <bool ZERO>
-__global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __restrict__ items, int W, int H, int tiles_x,
+__global__ __launch_bounds__(BLOCK) void k_prepass_batch(const ChunkTables tabs, int W, int H, int tiles_x,
                                                          long long plane, float4* __restrict__ rec,
                                                          float2* __restrict__ pool, float* __restrict__ chk,
                                                          float* __restrict__ xyz, float lambdaG,
                                                          unsigned long long* __restrict__ part,
                                                          unsigned long long* __restrict__ seg_mask, int nseg,
-                                                         unsigned* __restrict__ gmask, int mrow)
+                                                         unsigned* __restrict__ gmask, int mrow, int kf0,
+                                                         IngestItem* __restrict__ gitems)
 {
     __shared__ uint8_t t[PRE_HALO_H][PRE_HALO_W];
     __shared__ float gm[TILE_H + 1][TILE_W];
     __shared__ unsigned long long red[PART_WORDS * (BLOCK / 64)];
     const int kf = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint8_t* __restrict__ im = items[kf].img;
-    const int slot = items[kf].slot;
+    const int gkf = kf0 + kf;  // the keyframe's index in its GROUP of chunks (k_prepass_finish / k_list_write run once per group)
+    const IngestItem& item = chunk_item(tabs, kf);
+    const uint8_t* __restrict__ im = item.img;
+    const int slot = item.slot;
+    if (tile == 0 && tid == 0) gitems[gkf] = item;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
-    for (int i = tid; i < PRE_HALO_H * PRE_HALO_W; i += BLOCK) {  // replicated border
-        const int hy = i / PRE_HALO_W, hx = i - hy * PRE_HALO_W;
-        const int x = min(max(tx0 + hx - 1, 0), W - 1), y = min(max(ty0 + hy - 1, 0), H - 1);
-        t[hy][hx] = im[y * W + x];
+    const int lx = tid & (TILE_W - 1), wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: rows become scalar work)
+    for (int hy = wv; hy < PRE_HALO_H; hy += BLOCK / 64) {  // replicated border; a wave per halo row
+        const uint8_t* __restrict__ row = im + (long long)min(max(ty0 + hy - 1, 0), H - 1) * W;
+        t[hy][lx] = row[min(max(tx0 + lx - 1, 0), W - 1)];
+        if (lx < PRE_HALO_W - TILE_W) t[hy][TILE_W + lx] = row[min(max(tx0 + TILE_W + lx - 1, 0), W - 1)];
     }
     __syncthreads();
-    const int lx = tid & (TILE_W - 1), wv = tid >> 6;
     float th[PX_PER_THREAD];
-    unsigned long long acc[PART_WORDS] = {0ull, 0ull, 0ull, 0ull};
+    unsigned s1 = 0u, s2 = 0u;
+    unsigned long long hsum = 0ull;
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < PX_PER_THREAD; i++) {
         const int ly = i * (BLOCK / 64) + wv;
@@ -211,11 +269,11 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
         int centre;
         scharr32(t, lx, ly, gx, gy, centre);
         const float xx = gx * gx, yy = gy * gy;
-        gm[ly][lx] = sqrtf(xx + yy);
+        gm[ly][lx] = sqrt_grad(xx + yy);
         th[i] = fast_atan2_deg(gy, gx);
         if (tx0 + lx < W && ty0 + ly < H) {  // exact integer sums for I_stddev (any order gives the same total)
-            acc[0] += (unsigned long long)centre;
-            acc[1] += (unsigned long long)(centre * centre);
+            s1 += (unsigned)centre;
+            s2 += (unsigned)(centre * centre);
         }
     }
     if (wv == 0) {  // gradient row TILE_H of the tile = row 0 of the tile below: GradImg(y+1) of the last record row
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
         int centre;
         scharr32(t, lx, TILE_H, gx, gy, centre);
         const float xx = gx * gx, yy = gy * gy;
-        gm[TILE_H][lx] = sqrtf(xx + yy);
+        gm[TILE_H][lx] = sqrt_grad(xx + yy);
     }
     __syncthreads();
     const long long base = (long long)slot * plane;
@@ -232,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
         const int ly = i * (BLOCK / 64) + wv;
         const int x = tx0 + lx, y = ty0 + ly;
         const bool in = x < W && y < H;
-        bool gate = false, sgate = false;
+        bool gate = false, sgate = false, odd = false;
         if (in) {
             const bool below = y + 1 < H;
             const unsigned bits = (unsigned)t[ly + 1][lx + 1] | ((below ? (unsigned)t[ly + 2][lx + 1] : 0u) << 8);
@@ -246,27 +304,25 @@ __global__ __launch_bounds__(BLOCK) void k_prepass_batch(const IngestItem* __res
             if (ZERO) {
                 pool[o] = make_float2(0.f, 0.f);
                 chk[o] = 0.f;
-                if (xyz) {
-                    xyz[o * 3] = 0.f;
-                    xyz[o * 3 + 1] = 0.f;
-                    xyz[o * 3 + 2] = 0.f;
-                }
             }
             gate = act_gate(r.x, x, y, W, H, lambdaG);
             sgate = !(r.x < lambdaG);  // the scan's gate on this pixel as a CANDIDATE of another keyframe's search, PM.cc:411
-            if (gate) acc[2] += list_hash_term(((unsigned)y << 16) | (unsigned)x);
-            if (!(r.y >= 0.0f && r.y <= 360.0f)) acc[3] = 1ull;  // never from fastAtan2; kept for symmetry with k_pack
+            odd = !(r.y >= 0.0f && r.y <= 360.0f);  // never from fastAtan2; kept for symmetry with k_pack
+        }
+        bad = bad || __builtin_amdgcn_ballot_w64(odd) != 0ull;
+        if (ZERO && xyz && y < H) {  // the segment's 3 * 64 floats as dense dword stores
+            float* __restrict__ z = xyz + (base + (long long)y * W + tx0) * 3;
+            const int nz = 3 * min(TILE_W, W - tx0);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (lx + TILE_W * k < nz) z[lx + TILE_W * k] = 0.f;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        hsum += seg_hash_term(m, (unsigned)y, (unsigned)tx0);
+        if (lx == 0 && y < H) seg_mask[(long long)gkf * nseg + (long long)y * tiles_x + tx] = m;
         write_gate_planes(gmask, ((long long)slot * H + y) * MASK_PLANES * mrow, tx, sgate, th[i], y < H);
     }
-    block_sum4(acc, red);
-    if (tid < PART_WORDS) {
-        unsigned long long tot = 0;
-        for (int w = 0; w < BLOCK / 64; w++) tot += red[tid * (BLOCK / 64) + w];
-        part[((long long)kf * gridDim.x + tile) * PART_WORDS + tid] = tot;
-    }
+    tile_partials(s1, s2, hsum, bad, red, part + ((long long)gkf * gridDim.x + tile) * PART_WORDS);
 }
 
 // the same gate masks and hash from a slot's RECORDS (lists rebuilt under another lambdaG, or records packed from the
@@ -275,15 +331,18 @@ __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restri
                                                       long long plane, const float4* __restrict__ rec, float lambdaG,
                                                       unsigned long long* __restrict__ part,
                                                       unsigned long long* __restrict__ seg_mask, int nseg,
-                                                      unsigned* __restrict__ gmask, int mrow)
+                                                      unsigned* __restrict__ gmask, int mrow, int kf0,
+                                                      IngestItem* __restrict__ gitems)
 {
     __shared__ unsigned long long red[PART_WORDS * (BLOCK / 64)];
     const int kf = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int gkf = kf0 + kf;
     const int slot = items[kf].slot;
+    if (tile == 0 && tid == 0) gitems[gkf] = items[kf];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int lx = tid & (TILE_W - 1), wv = tid >> 6;
+    const int lx = tid & (TILE_W - 1), wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float4* __restrict__ r = rec + (long long)slot * plane;
-    unsigned long long acc[PART_WORDS] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long hsum = 0ull;
 #pragma unroll
     for (int i = 0; i < PX_PER_THREAD; i++) {
         const int x = tx * TILE_W + lx, y = ty * TILE_H + i * (BLOCK / 64) + wv;
@@ -295,27 +354,25 @@ __global__ __launch_bounds__(BLOCK) void k_gate_batch(const IngestItem* __restri
             sgate = !(rr.x < lambdaG);
             theta = rr.y;
         }
-        if (gate) acc[2] += list_hash_term(((unsigned)y << 16) | (unsigned)x);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
-        if (lx == 0 && y < H) seg_mask[(long long)kf * nseg + (long long)y * tiles_x + tx] = m;
+        hsum += seg_hash_term(m, (unsigned)y, (unsigned)(tx * TILE_W));
+        if (lx == 0 && y < H) seg_mask[(long long)gkf * nseg + (long long)y * tiles_x + tx] = m;
         write_gate_planes(gmask, ((long long)slot * H + y) * MASK_PLANES * mrow, tx, sgate, theta, y < H);
     }
-    block_sum4(acc, red);
-    if (tid < PART_WORDS) {
-        unsigned long long tot = 0;
-        for (int w = 0; w < BLOCK / 64; w++) tot += red[tid * (BLOCK / 64) + w];
-        part[((long long)kf * gridDim.x + tile) * PART_WORDS + tid] = tot;
-    }
+    tile_partials(0u, 0u, hsum, false, red, part + ((long long)gkf * gridDim.x + tile) * PART_WORDS);
 }
 
-// One workgroup per keyframe.  full != 0 (a keyframe was uploaded): I_stddev = population sigma of im (PM.cc:457) from
+// One workgroup per keyframe of a group of chunks (items = the group's table, filled by the chunks' first kernels).  The list
+// length also goes straight into the host's pinned mirror (host_count: device-visible host memory; the host reads it behind an
+// event recorded after this kernel).  full != 0 (a keyframe was uploaded): I_stddev = population sigma of im (PM.cc:457) from
 // the tile sums, the slot's metadata and its theta flag are written; otherwise only the list (length, hash, offsets).
 constexpr int FIN_BLOCK = 1024;
 __global__ __launch_bounds__(FIN_BLOCK) void k_prepass_finish(const IngestItem* __restrict__ items, int W, int H, int ntiles,
                                                               int nseg, const unsigned long long* __restrict__ part,
                                                               const unsigned long long* __restrict__ seg_mask,
                                                               int* __restrict__ seg_off, KfMeta* __restrict__ meta,
-                                                              int* __restrict__ act_count, int* __restrict__ theta_bad,
+                                                              int* __restrict__ act_count, int* __restrict__ host_count,
+                                                              int* __restrict__ theta_bad,
                                                               unsigned long long* __restrict__ act_hash, int full)
 {
     __shared__ unsigned long long red[PART_WORDS][FIN_BLOCK / 64];
@@ -362,6 +419,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_prepass_finish(const IngestItem* 
             for (int w = 0; w < FIN_BLOCK / 64; w++) tot[k] += red[k][w];
         }
         act_count[it.slot] = total;
+        host_count[it.slot] = total;
         act_hash[it.slot] = tot[2];
         if (full) {
             KfMeta m = it.meta;
@@ -380,19 +438,34 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_prepass_finish(const IngestItem* 
     }
 }
 
-// one wave per row segment: the set bits of its mask, at the segment's raster-order offset
+// one wave per LIST_SEGS consecutive row segments: the set bits of their masks, at the segments' raster-order offsets
+constexpr int LIST_SEGS = 16;
 __global__ __launch_bounds__(BLOCK) void k_list_write(const IngestItem* __restrict__ items, int tiles_x, int nseg,
                                                       long long plane, const unsigned long long* __restrict__ seg_mask,
                                                       const int* __restrict__ seg_off, unsigned* __restrict__ act)
 {
     const int kf = blockIdx.y;
-    const int s = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= nseg) return;
-    const unsigned long long m = seg_mask[(long long)kf * nseg + s];
-    if (!((m >> lane) & 1ull)) return;
-    const int y = s / tiles_x, x = (s - y * tiles_x) * TILE_W + lane;
-    const int off = seg_off[(long long)kf * nseg + s] + __popcll(m & ((1ull << lane) - 1ull));
-    act[(long long)items[kf].slot * plane + off] = ((unsigned)y << 16) | (unsigned)x;
+    const int s0 = (blockIdx.x * (BLOCK / 64) + (int)(threadIdx.x >> 6)) * LIST_SEGS, lane = threadIdx.x & 63;
+    if (s0 >= nseg) return;
+    const int mine = min(s0 + (lane & (LIST_SEGS - 1)), nseg - 1);
+    const unsigned long long mm = seg_mask[(long long)kf * nseg + mine];
+    const int mo = seg_off[(long long)kf * nseg + mine];
+    unsigned* __restrict__ out = act + (long long)items[kf].slot * plane;
+    int y = s0 / tiles_x, tx = s0 - y * tiles_x;
+#pragma unroll
+    for (int j = 0; j < LIST_SEGS; j++) {
+        if (s0 + j < nseg) {  // wave-uniform
+            const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mm >> 32), j) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)mm, j);
+            const int off = __builtin_amdgcn_readlane(mo, j);
+            if ((m >> lane) & 1ull)
+                out[off + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)y << 16) | (unsigned)(tx * TILE_W + lane);
+        }
+        if (++tx == tiles_x) {
+            tx = 0;
+            y++;
+        }
+    }
 }
 
 // pack im/grad/theta planes into the 16-byte search records (layout: sdm_device.h): the caller's own planes

@@ -243,20 +243,29 @@ def allgather_boundary(pool, pl, group=None):
 # ---- the compact wire format on host arrays ------------------------------------------------------------------------------
 # What crosses ranks per map with sdm_exchange_compact(entries): the {rho,sigma} of the keyframe's active-list entries in
 # list order, then a header of XCHG_HEADER float2 -- the list length and the 64-bit hash of the list as bit patterns
-# (csrc/sdm_comm.h k_pack_lists / k_unpack_lists, csrc/sdm_ingest.h list_hash_term).  The numpy statement below is the
+# (csrc/sdm_comm.h k_pack_lists / k_unpack_lists, csrc/sdm_ingest.h seg_hash_term).  The numpy statement below is the
 # format's second implementation: the CPU tests move it between processes over gloo, the GPU tests check it against the
 # engine's own packing byte for byte.
 XCHG_HEADER = 8
 
 
 def list_hash(lst):
-    """sum over the list's (y << 16 | x) of their SplitMix64 finalisation, mod 2^64"""
+    """hash of the pixel set the list holds: over the 64-pixel row segments it touches, the sum (mod 2^64) of the SplitMix64
+    finalisation of (the segment's 64-bit membership mask) xor ((y << 16 | x0) * 0x9E3779B97F4A7C15), x0 = the segment's
+    first column (csrc/sdm_ingest.h seg_hash_term)"""
     import numpy as np
-    z = np.asarray(lst, np.uint32).astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    z = z ^ (z >> np.uint64(31))
-    return int(z.sum(dtype=np.uint64))
+    lst = np.asarray(lst, np.uint32).ravel()
+    if lst.size == 0:
+        return 0
+    keys, inv = np.unique(lst & ~np.uint32(63), return_inverse=True)
+    masks = np.zeros(keys.size, np.uint64)
+    np.bitwise_or.at(masks, inv.ravel(), np.uint64(1) << (lst & np.uint32(63)).astype(np.uint64))
+    with np.errstate(over="ignore"):
+        z = masks ^ (keys.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(z.sum(dtype=np.uint64))
 
 
 def pack_compact(depth_map, lst, entries):

@@ -101,12 +101,19 @@ def np_active_list(grad, lambdaG=8.0):
 
 
 def np_list_hash(lst):
-    """the compact wire header's hash (csrc/sdm_ingest.h list_hash_term): sum of SplitMix64-finalised (y << 16 | x)"""
-    z = lst.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    z = z ^ (z >> np.uint64(31))
-    return int(z.sum(dtype=np.uint64))
+    """the compact wire header's hash (csrc/sdm_ingest.h seg_hash_term), restated with plain integers: per 64-pixel row segment
+    with listed pixels, SplitMix64's finaliser of mask ^ ((y << 16 | x0) * golden), summed mod 2^64"""
+    M = (1 << 64) - 1
+    segs = {}
+    for v in lst.tolist():
+        segs[v & ~63] = segs.get(v & ~63, 0) | (1 << (v & 63))
+    tot = 0
+    for key, mask in segs.items():
+        z = mask ^ ((key * 0x9E3779B97F4A7C15) & M)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        tot = (tot + (z ^ (z >> 31))) & M
+    return tot
 
 
 @pytest.mark.parametrize("W,H,n_kf", [(160, 120, 8), (75, 53, 5), (640, 480, 70)])

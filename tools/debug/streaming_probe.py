@@ -22,7 +22,7 @@ poses = [wl.scene.Tcw(k) for k in ks]
 gc.disable()
 AHEAD = int(os.environ.get("AHEAD", "3"))
 for overlap in (False, True):
-    eng = pkg.Engine(wl.W, wl.H, AHEAD * n_slots, max_neighbours=wl.N, batch_capacity=64, with_pointset=True)
+    eng = pkg.Engine(wl.W, wl.H, AHEAD * n_slots, max_neighbours=wl.N, batch_capacity=64, with_pointset=os.environ.get("POINTSET", "1") == "1")
     eng.set_ingest_overlap(overlap)
     shift = lambda lst, off: [s_ + off for s_ in lst]
     pls = [dict(pl, own_slots=shift(pl["own_slots"], h * n_slots), nbr_slots=[shift(r, h * n_slots) for r in pl["nbr_slots"]]) for h in range(AHEAD)]
