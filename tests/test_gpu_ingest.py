@@ -116,11 +116,14 @@ def np_list_hash(lst):
     return tot
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("W,H,n_kf", [(160, 120, 8), (75, 53, 5), (640, 480, 70)])
-def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf):
+def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf, overlap):
     """sdm_upload_images_batch (one launch of each pre-pass kernel over (keyframe, tile), chunked, H2D on the upload
     stream; pageable AND pinned sources, non-consecutive slots) against one sdm_upload_image call per keyframe and
-    against the oracle's pre-pass: records, I_stddev, the active-pixel lists and their hashes, bit for bit."""
+    against the oracle's pre-pass: records, I_stddev, the active-pixel lists and their hashes, bit for bit.
+    overlap: the streaming ingest's launch shape (one pre-pass launch per group of four chunks; 67 keyframes = five chunks =
+    a full group and a one-chunk group)."""
     rng = np.random.default_rng(W * 31 + n_kf)
     yy, xx = np.mgrid[0:H, 0:W]
     ims = [np.clip(127 + 90 * np.sin(xx / (5.0 + k)) * np.cos(yy / 4.0) + rng.integers(-25, 25, (H, W)), 0, 255).astype(np.uint8)
@@ -140,7 +143,8 @@ def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf):
     pinned = [bat.host_alloc((H, W)) for _ in range(n_kf)]
     for k in range(n_kf):
         pinned[k][...] = ims[k]
-    half = n_kf // 2
+    bat.set_ingest_overlap(overlap)
+    half = min(3, n_kf // 2) if overlap else n_kf // 2
     bat.upload_images_batch(slots[:half], pinned[:half], K, poses[:half])      # read in place by the copy engine
     bat.upload_images_batch(slots[half:], ims[half:], K, poses[half:])         # pageable: through the pinned ring
     for k in list(range(min(n_kf, 6))) + [n_kf - 1]:
