@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs (N=1 only)")
     ap.add_argument("--no-streaming", action="store_true", help="skip the sustained ingest + compute figure (N=1 only)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child runs (then: the committed PMC file, or null)")
     ap.add_argument("--exchange", default="allgather", choices=["halo", "allgather", "allgather_late", "allgather_full"],
                     help="N>1: the exchange of {rho,sigma} maps between K3 and K4 that `value` is measured with: "
                          "allgather = RCCL all-gather of the maps that cross ranks (every rank's boundary keyframes, "
@@ -100,6 +102,74 @@ def self_launch(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def under_profiler():
+    return any(("rocprof" in os.environ.get(k, "").lower()) for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+        any(k.startswith("ROCPROF") for k in os.environ)
+
+
+LIVE_PMC_GROUPS = (("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"),
+                   ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+
+
+def live_traffic(args):
+    """HBM-side bytes of one k_search_fuse launch, measured in THIS run: one `rocprofv3 --pmc` child per counter group (no
+    trace domains; the read-request sizes and the write requests cannot share a pass) over two steps of the same workload,
+    started before this process touches the GPU (a GPU process must not exec, and two processes would share the card).
+    bytes = 32 n32 + 64 n64 + 128 n128 (+ 64 w64 + 32 (w - w64)): TCC_EA0 counters summed over channels, averaged over the
+    kernel's dispatches -- tools/pmc_summary.py's arithmetic, the guide's "calibrate on your own access pattern".
+    Returns (record or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    if args.no_live_pmc or os.environ.get("SDM_BENCH_PMC_CHILD") or under_profiler():
+        return None, "live PMC passes skipped (flag, child run, or already under a profiler)"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    flags = ["--kfs", str(args.kfs), "--nbrs", str(args.nbrs), "--res", args.res, "--disparity", repr(args.disparity),
+             "--prior-spread", repr(args.prior_spread), "--scene", args.scene, "--roll", repr(args.roll),
+             "--outliers", str(args.outliers)] + (["--noise"] if args.noise else [])
+    child = ["python3", os.path.abspath(__file__)] + flags + ["--steps", "2", "--warmup", "1", "--cpu-kfs", "0", "--no-stats",
+                                                               "--no-extra", "--no-streaming", "--no-live-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp", SDM_BENCH_PMC_CHILD="1")
+    out = tempfile.mkdtemp(prefix="sdm_live_pmc_", dir="/tmp")
+    acc = {}
+    try:
+        for g, group in enumerate(LIVE_PMC_GROUPS):
+            d = os.path.join(out, "p%d" % g)
+            cmd = [exe, "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--"] + child
+            with open(os.path.join(out, "p%d.log" % g), "wb") as log:
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+                try:
+                    rc = pr.wait(timeout=240)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)  # the process group this call started, nothing else
+                    pr.wait()
+                    return None, "live PMC pass %d timed out" % g
+            if rc != 0:
+                return None, "live PMC pass %d exited with %d" % (g, rc)
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_search_fuse<false" in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        c = {k: sum(v) / len(v) for k, v in acc.items()}
+        need = LIVE_PMC_GROUPS[0] + LIVE_PMC_GROUPS[1]
+        if not all(k in c for k in need):
+            return None, "live PMC passes returned no k_search_fuse rows for %s" % [k for k in need if k not in c]
+        rd = 32 * c[need[0]] + 64 * c[need[1]] + 128 * c[need[2]]
+        wr = 64 * c["TCC_EA0_WRREQ_64B_sum"] + 32 * (c["TCC_EA0_WRREQ_sum"] - c["TCC_EA0_WRREQ_64B_sum"])
+        return {"traffic": rd + wr, "read": rd, "write": wr, "dispatches": len(acc[need[0]])}, \
+            "live: %d rocprofv3 --pmc passes (TCC_EA0 read-request sizes; write requests) over a 2-step child run of this " \
+            "workload, started by this bench.py before it touched the GPU; averaged over %d dispatches" % (
+                len(LIVE_PMC_GROUPS), len(acc[need[0]]))
+    except Exception as e:  # never let the measurement of one field break the bench line
+        return None, "live PMC passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def source_hash():
@@ -218,6 +288,8 @@ def prewarm(wl, barrier, exchange, transport, reduce_max=None):
     if reduce_max is not None:
         t = reduce_max(t)
     n = int(min(400, max(4, PREWARM_S / max(t, 1e-5))))
+    if os.environ.get("SDM_BENCH_PMC_CHILD"):
+        n = 4  # counter passes: every dispatch is serialised and read out, and clocks do not change byte counts
     for _ in range(n):
         wl.step(exchange, transport)
     wl.torch.cuda.synchronize()
@@ -241,7 +313,7 @@ def timed(wl, steps, warmup, barrier, exchange, transport):
     return dt, timing
 
 
-def roofline(wl, timing, steps, traffic):
+def roofline(wl, timing, steps, traffic, traffic_source=None):
     """K1's roofline record.  `achieved` = ALGORITHMIC bytes (P*(17+9N) per reference
     keyframe x the keyframes one launch covers) / the launch's HIP-event duration; `traffic` = HBM-side bytes
     per launch from the PMC run of the same build and workload (null otherwise); hbm_GBs = traffic / duration."""
@@ -264,7 +336,8 @@ def roofline(wl, timing, steps, traffic):
     if traffic:
         out["hbm_GBs"] = round(traffic / (k1_avg_ms * 1e-3) / 1e9, 1)
         out["hbm_frac"] = round(out["hbm_GBs"] / HBM_PEAK_GBS, 4)
-        out["traffic_source"] = "profiles/ PMC run (rocprofv3 --pmc, TCC_EA0 request counters) of this build and workload"
+        out["traffic_source"] = traffic_source or \
+            "profiles/ PMC run (rocprofv3 --pmc, TCC_EA0 request counters) of this build and workload"
     return out, k1_avg_ms
 
 
@@ -366,6 +439,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    live, live_note = (None, "multi-rank run") if (args.gpus > 1 or args.independent) else live_traffic(args)
 
     import torch
     import torch.distributed as dist
@@ -553,11 +627,17 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = P * n_total * args.steps / dt / 1e6
-    rf, k1_avg_ms = roofline(wl, timing, args.steps,
-                             committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps,
-                                               noise=args.noise, outliers=args.outliers, spread=args.prior_spread,
-                                               strip=(args.scene == "strip"), roll=args.roll)
-                             if world == 1 else None)
+    committed = committed_traffic(args.res, args.kfs, N, args.disparity, timing["search_fuse"][1], args.steps,
+                                  noise=args.noise, outliers=args.outliers, spread=args.prior_spread,
+                                  strip=(args.scene == "strip"), roll=args.roll) if world == 1 else None
+    if live and timing["search_fuse"][1] == args.steps:  # (one K1 launch per step, as in the child run)
+        rf, k1_avg_ms = roofline(wl, timing, args.steps, live["traffic"], live_note)
+        rf["traffic_read"], rf["traffic_write"] = live["read"], live["write"]
+        if committed:
+            rf["traffic_committed_profile"] = committed  # the same figure from profiles/*_traffic.json (same source hash)
+    else:
+        rf, k1_avg_ms = roofline(wl, timing, args.steps, committed)
+        rf["traffic_note"] = live_note
     rf_cold, _ = roofline(wl, timing_cold, args.steps, None)
     rf["frac_cold"] = rf_cold["frac"]  # the same K steps after only the W warm-up steps (no pre-warm phase)
     rf["launch_ms_cold"] = rf_cold["launch_ms"]

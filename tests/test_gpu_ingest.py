@@ -140,6 +140,8 @@ def test_batch_upload_equals_single_uploads(pkg, oracle, gpu_ok, W, H, n_kf, ove
     for s in slots[:3]:
         bat.upload_image(s, ims[0], K, EYE)
         bat.upload_depth(s, np.full((H, W), 0.7, np.float32), np.full((H, W), 0.1, np.float32))
+        bat.pointset([s], source=0)  # every pixel of the point-set plane non-zero
+        assert bat.download_pointset(s).any()
     pinned = [bat.host_alloc((H, W)) for _ in range(n_kf)]
     for k in range(n_kf):
         pinned[k][...] = ims[k]

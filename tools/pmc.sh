@@ -13,7 +13,7 @@ i=0
 while IFS= read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --cpu-kfs 0 --no-stats --no-extra --no-streaming "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed"
+  timeout -k 10 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --cpu-kfs 0 --no-stats --no-extra --no-streaming --no-live-pmc "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed"
 done <<'GROUPS'
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum
