@@ -309,7 +309,8 @@ int sdm_get_stats(sdm_ctx *ctx, sdm_stats *out, int reset);
 int sdm_set_scan_mode(sdm_ctx *ctx, int mode);
 /* Streaming ingest (default off).  On: the batched uploads (sdm_upload_images_batch / _rgb_batch) get twelve chunk buffers
  * instead of four, so the host staging and the H2D copies (upload stream) of up to three 64-keyframe blocks run ahead of
- * their pre-pass kernels, which stay on the compute stream in call order.  A block uploaded BEFORE the previous block's step
+ * their pre-pass kernels, which stay on the compute stream in call order (and, the copies being ahead anyway, run as ONE
+ * launch per group of four chunks behind one wait for the group's last copy).  A block uploaded BEFORE the previous block's step
  * is queued (double-buffer the slot sets: bench.py streaming_rate; frames arrive continuously in the fork,
  * src/Tracking.cc:266-271) is then copied while that step runs, pre-processed right behind it, and its list lengths are back
  * before its own step is queued (every compute call waits for the list lengths of ITS slots only, with or without this

@@ -300,3 +300,57 @@ def test_overlapped_ingest_into_slots_in_use(pkg, oracle, gpu_ok):
                 assert_bit_equal(got[k][0], r, "rep %d rho kf %d" % (rep, k))
                 assert_bit_equal(got[k][1], s, "rep %d sigma kf %d" % (rep, k))
     eng.close()
+
+
+_INGEST_SIZES = int(__import__("os").environ.get("SDM_FUZZ_INGEST", "8"))
+
+
+def test_prepass_random_sizes(pkg, oracle, gpu_ok):
+    """The batched pre-pass on random image sizes (widths that are no multiple of the 64-pixel tile, images smaller than a
+    tile), random images (flat patches, saturated patches, noise), both launch shapes, into slots whose planes are dirty:
+    records, I_stddev, list, hash against the oracle's pre-pass; maps, checked plane and point set start as zeros.
+    SDM_FUZZ_INGEST = number of cases (deep runs: tools/run_deepfuzz_r05.sh)."""
+    rng = np.random.default_rng(20261005)
+    for case in range(_INGEST_SIZES):
+        W, H = int(rng.integers(5, 300)), int(rng.integers(5, 200))
+        n_kf = int(rng.integers(1, 10))
+        ims = []
+        for k in range(n_kf):
+            im = rng.integers(0, 256, (H, W)).astype(np.uint8)
+            kind = int(rng.integers(0, 4))
+            if kind == 0:  # smooth ramp + a little noise: the usual 20 %-dense list
+                yy, xx = np.mgrid[0:H, 0:W]
+                im = np.clip(127 + 100 * np.sin(xx / 7.0 + k) * np.cos(yy / 5.0) + rng.integers(-6, 6, (H, W)), 0, 255).astype(np.uint8)
+            elif kind == 1:  # flat and saturated patches (zero gradients, maximal gradients)
+                im[: H // 2, : W // 2] = int(rng.integers(0, 256))
+                im[H // 2:, W // 2:] = 255 * (np.indices((H - H // 2, W - W // 2)).sum(0) & 1)
+            elif kind == 2:
+                im[...] = int(rng.integers(0, 256))  # nothing listed
+            ims.append(im)
+        K = TUM1_K * np.float32(W / 640.0)
+        poses = [EYE] * n_kf
+        eng = pkg.Engine(W, H, n_kf + 2)
+        overlap = bool(case & 1)
+        eng.set_ingest_overlap(overlap)
+        slots = list(rng.permutation(n_kf + 2)[:n_kf])
+        dirty = slots[0]
+        eng.upload_image(dirty, ims[-1], K, EYE)
+        eng.upload_depth(dirty, np.full((H, W), 0.7, np.float32), np.full((H, W), 0.1, np.float32))
+        eng.pointset([dirty], source=0)
+        eng.upload_images_batch(slots, ims, K, poses)
+        for k in range(n_kf):
+            im_b, g, t, sd = eng.download_inputs(slots[k])
+            wg, wt, ws = oracle.gradient_prepass(ims[k])
+            tag = "case %d (%dx%d, %d kf, overlap %d) kf %d" % (case, W, H, n_kf, overlap, k)
+            assert (im_b == ims[k]).all(), tag
+            assert_bit_equal(g, wg, "GradImg " + tag)
+            assert_bit_equal(t, wt, "GradTheta " + tag)
+            assert np.float32(sd) == np.float32(ws), tag
+            lst, h = eng.active_list(slots[k])
+            want = np_active_list(wg)
+            assert lst.size == want.size and (lst == want).all(), tag
+            assert h == np_list_hash(want) == pkg.shard.list_hash(want), tag
+            r, s = eng.download_depth(slots[k])
+            assert not r.any() and not s.any(), tag
+            assert not eng.download_pointset(slots[k]).any(), tag
+        eng.close()
