@@ -130,6 +130,8 @@ def live_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
+    if not os.path.exists("/dev/kfd"):
+        return None, "no GPU device node"
     flags = ["--kfs", str(args.kfs), "--nbrs", str(args.nbrs), "--res", args.res, "--disparity", repr(args.disparity),
              "--prior-spread", repr(args.prior_spread), "--scene", args.scene, "--roll", repr(args.roll),
              "--outliers", str(args.outliers)] + (["--noise"] if args.noise else [])
