@@ -312,7 +312,7 @@ def test_prepass_random_sizes(pkg, oracle, gpu_ok):
     SDM_FUZZ_INGEST = number of cases (deep runs: tools/run_deepfuzz_r05.sh)."""
     rng = np.random.default_rng(20261005)
     for case in range(_INGEST_SIZES):
-        W, H = int(rng.integers(5, 300)), int(rng.integers(5, 200))
+        W, H = int(rng.integers(8, 300)), int(rng.integers(8, 200))  # (the engine takes 8 x 8 and up)
         n_kf = int(rng.integers(1, 10))
         ims = []
         for k in range(n_kf):
