@@ -1294,7 +1294,11 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     }
     const int hw = (int)std::thread::hardware_concurrency();
     const int n_chunks = (n + cap - 1) / cap;
-    Stager stager((pageable_bytes >= ((size_t)2 << 20) && hw >= 4) ? std::min(4, hw / 2) : 1, n_chunks);
+    static const int max_stagers = [] {  // A/B knob, read once per process (default 4: tools/debug/upload_probe.py)
+        const char* e = getenv("SDM_STAGER_THREADS");
+        return e ? std::max(1, std::min(16, atoi(e))) : 4;
+    }();
+    Stager stager((pageable_bytes >= ((size_t)2 << 20) && hw >= 4) ? std::min(max_stagers, hw / 2) : 1, n_chunks);
     // one chunk (a single new keyframe, the online use): nothing to overlap with, so its copies stay on the compute stream
     // and no cross-stream hand-over is paid; more chunks: copies on the upload stream, kernels behind an event
     const hipStream_t cs = n_chunks > 1 ? c->up_stream : c->stream;
