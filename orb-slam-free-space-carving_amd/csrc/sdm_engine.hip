@@ -88,7 +88,7 @@ struct sdm_ctx {
     unsigned grow_capacity = 0;
     unsigned grow_launch = 0;
     unsigned k4_lds_pad = 0;  // experiment knob (SDM_K4_PAD): dynamic LDS requested by K4's list kernel = an occupancy cap
-    int* h_act_count = nullptr;    // pinned host mirror, filled by asynchronous copies
+    int* h_act_count = nullptr;    // pinned host mirror (device-visible): k_prepass_finish stores the lengths into it, read behind the cnt_ev events
     std::vector<float> act_lambdaG;  // lambdaG each list was built with (NaN = no list)
     std::vector<char> chk_sparse, xyz_sparse;  // checked / xyz plane of the slot is zero outside its active list
     std::vector<float> recon_lambdaG;  // lambdaG a slot's depth map was reconstructed with (NaN = map
@@ -1410,7 +1410,7 @@ int ingest_images_impl(sdm_ctx* c, int n, const int* slots, const uint8_t* const
     }
     // the caller's buffers are free on return: pageable images were copied into the ring; copies that read pinned images
     // in place are awaited here (the pre-pass kernels are not)
-    if ((rc = counts_queued(c, n, slots))) return rc;  // one event behind the last chunk's read-back
+    if ((rc = counts_queued(c, n, slots))) return rc;  // one event behind the last group's kernels (they store the list lengths)
     const double t_tail = dbg ? now() : 0.0;
     if (direct && last >= 0) {
         HIP_TRY(hipEventSynchronize(c->ing[last].copied));
