@@ -283,3 +283,46 @@ def test_boundary_allgather_lists(pkg):
         # the collective moves (world - 1) * contrib_count maps per rank instead of (world - 1) * block
         assert plans[0]["contrib_count"] <= min(n, n_total // world)
     assert shard.sub_blocks(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)] and shard.sub_blocks(3, 8) == [(0, 1), (1, 1), (2, 1)]
+
+
+def test_list_hash_definition(pkg):
+    """shard.list_hash (numpy) against the definition spelled out with Python integers (csrc/sdm_ingest.h seg_hash_term): per
+    64-pixel row segment with listed pixels, SplitMix64's finaliser of mask ^ ((y << 16 | x0) * 0x9E3779B97F4A7C15), summed
+    mod 2^64; order-independent; sensitive to one pixel moving inside a segment, across segments and across rows; a known
+    answer pins the constants."""
+    shard = pkg.shard
+    M = (1 << 64) - 1
+
+    def by_definition(lst):
+        segs = {}
+        for v in np.asarray(lst, np.uint32).tolist():
+            segs[v & ~63] = segs.get(v & ~63, 0) | (1 << (v & 63))
+        tot = 0
+        for key, mask in segs.items():
+            z = mask ^ ((key * 0x9E3779B97F4A7C15) & M)
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            tot = (tot + (z ^ (z >> 31))) & M
+        return tot
+
+    rng = np.random.default_rng(11)
+    assert shard.list_hash(np.zeros(0, np.uint32)) == 0
+    assert shard.list_hash(np.uint32([(2 << 16) | 2])) == by_definition([(2 << 16) | 2]) == 0xC6AC4D8F8B52AE06  # known answer
+    for n in (1, 2, 63, 64, 65, 1000, 50000):
+        ys, xs = rng.integers(2, 478, n), rng.integers(2, 638, n)
+        lst = np.unique((ys.astype(np.uint32) << 16) | xs.astype(np.uint32))
+        h = shard.list_hash(lst)
+        assert h == by_definition(lst)
+        assert shard.list_hash(lst[::-1].copy()) == h  # a set hash
+        moved = lst.copy()
+        moved[0] ^= 1  # the neighbouring column (same segment)
+        if moved[0] not in lst[1:]:
+            assert shard.list_hash(moved) != h
+        moved = lst.copy()
+        moved[0] ^= 64  # the same bit of the neighbouring segment
+        if moved[0] not in lst[1:]:
+            assert shard.list_hash(moved) != h
+        moved = lst.copy()
+        moved[0] ^= 1 << 16  # the neighbouring row
+        if moved[0] not in lst[1:]:
+            assert shard.list_hash(moved) != h
