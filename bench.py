@@ -327,7 +327,9 @@ def roofline(wl, timing, steps, traffic, traffic_source=None):
         # what the counters say bounds the kernel (profiles/*_pmc.txt): the vector ALU's issue slots are
         # ~85 % full while the HBM pins carry ~0.2 of their peak.  achieved / peak / frac stay SURVEY.md §8d's figure:
         # ALGORITHMIC bytes per launch over the launch time, against the HBM peak.
-        "bound": "valu-issue", "model": "hbm (SURVEY.md §8d algorithmic bytes / HBM peak)", "kernel": "k_search_fuse",
+        # `bound` names the roofline `achieved` / `peak` / `frac` are priced against (the bench contract's "hbm" | "mfma");
+        # `limiter` = what the kernel's own counters say holds it back
+        "bound": "hbm", "model": "hbm (SURVEY.md §8d algorithmic bytes / HBM peak)", "kernel": "k_search_fuse",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
